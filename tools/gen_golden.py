@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference's own modules.
+
+Runs only in the build container (needs /root/reference); the GPU box gets the
+committed arrays.  What is imported from the reference, unmodified:
+  model/shift.py   (_GSM, GatedShift, TemporalShift, InplaceShift, make_temporal_shift)
+  model/modules.py (GRUPrediction, FCPrediction)
+  model/common.py  (MLP, step)
+  model/min_gru.py (MinRNNPredictor)
+  util/score.py    (filter_events_by_score, non_max_suppression_events)
+model/shift.py imports torchvision and timm only for isinstance() checks; both are
+absent here, so placeholder modules carrying those class names are registered first,
+and `ftens` (torch.cuda.FloatTensor, cannot construct without a GPU) is replaced by a
+CPU zeros constructor.  The RegNet-Y backbone is not part of the reference (timm):
+fixture `full_model` therefore composes the reference's shift insertion and heads
+with the oracle's RegNet-Y.
+
+Weights and inputs come from seeded generators; the arrays stored are the inputs that
+are cheap to store and every output.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("STES_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle import stes_oracle as O  # noqa: E402
+
+
+def _install_placeholders():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    class _Never(nn.Module):
+        pass
+
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.models.resnet = mod("torchvision.models.resnet")
+    tv.models.resnet.BasicBlock = _Never
+    tv.models.ResNet = _Never
+    tv.ops = mod("torchvision.ops")
+    tv.ops.misc = mod("torchvision.ops.misc")
+    tv.ops.misc.ConvNormActivation = _Never
+    tm = mod("timm")
+    tm.layers = mod("timm.layers")
+    tm.layers.conv_bn_act = mod("timm.layers.conv_bn_act")
+    tm.layers.conv_bn_act.ConvBnAct = O.ConvBnAct      # oracle class stands where timm's would
+    tm.models = mod("timm.models")
+    tm.models.regnet = mod("timm.models.regnet")
+    tm.models.regnet.RegNet = O.RegNetY
+    tm.models.convnext = mod("timm.models.convnext")
+    tm.models.convnext.ConvNeXt = _Never
+
+
+_install_placeholders()
+import model.shift as RS  # noqa: E402  (reference)
+import model.modules as RM  # noqa: E402
+import model.common as RC  # noqa: E402
+import model.min_gru as RG  # noqa: E402
+import util.score as RSC  # noqa: E402
+
+RS.ftens = lambda *s: torch.zeros(*s)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                           for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v.detach() if isinstance(v, torch.Tensor) else v).shape)
+                          for k, v in arrs.items()})
+
+
+def gen_gsm():
+    """_GSM forward + backward, train and eval BN, random and zero gate."""
+    for fold, t, h, w, b in ((8, 4, 5, 6, 2), (16, 3, 4, 4, 2), (32, 4, 3, 3, 1), (80, 2, 2, 3, 2), (192, 3, 2, 2, 1)):
+        for mode in ("train", "eval"):
+            for gate in ("rand", "zero"):
+                g = torch.Generator().manual_seed(1000 + fold)
+                m = RS._GSM(fold, t)
+                with torch.no_grad():
+                    if gate == "rand":
+                        m.conv3D.weight.copy_(torch.randn(m.conv3D.weight.shape, generator=g) * 0.2)
+                        m.conv3D.bias.copy_(torch.randn(2, generator=g) * 0.1)
+                    m.bn.weight.copy_(1 + 0.3 * torch.randn(fold, generator=g))
+                    m.bn.bias.copy_(0.2 * torch.randn(fold, generator=g))
+                    m.bn.running_mean.copy_(0.2 * torch.randn(fold, generator=g))
+                    m.bn.running_var.copy_(0.5 + torch.rand(fold, generator=g))
+                rm0, rv0 = m.bn.running_mean.clone(), m.bn.running_var.clone()
+                m.train(mode == "train")
+                x = torch.randn(b * t, fold, h, w, generator=g, requires_grad=True)
+                gy = torch.randn(b * t, fold, h, w, generator=g)
+                y = m(x)
+                y.backward(gy)
+                save(f"gsm_f{fold}_{mode}_{gate}", x=x, gy=gy, y=y, gx=x.grad, T=t,
+                     conv_w=m.conv3D.weight, conv_b=m.conv3D.bias, g_conv_w=m.conv3D.weight.grad,
+                     g_conv_b=m.conv3D.bias.grad, bn_w=m.bn.weight, bn_b=m.bn.bias,
+                     g_bn_w=m.bn.weight.grad, g_bn_b=m.bn.bias.grad,
+                     rm0=rm0, rv0=rv0, rm1=m.bn.running_mean, rv1=m.bn.running_var)
+
+
+def gen_gated_shift():
+    """GatedShift around a plain 1x1 nn.Conv2d (model/shift.py:145-146 branch)."""
+    g = torch.Generator().manual_seed(7)
+    conv = nn.Conv2d(32, 16, 1, bias=False)
+    gs = RS.GatedShift(conv, n_segment=4, n_div=4)
+    with torch.no_grad():
+        gs.gsm.conv3D.weight.copy_(torch.randn(gs.gsm.conv3D.weight.shape, generator=g) * 0.2)
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2)
+    gs.eval()
+    x = torch.randn(8, 32, 4, 4, generator=g)
+    save("gated_shift", x=x, y=gs(x), fold=gs.fold_dim, conv_w=conv.weight, gsm_w=gs.gsm.conv3D.weight,
+         gsm_b=gs.gsm.conv3D.bias)
+
+
+def gen_tsm():
+    g = torch.Generator().manual_seed(11)
+    for c, t, h, w, b in ((32, 4, 3, 3, 2), (64, 5, 2, 2, 1), (320, 3, 2, 2, 2)):
+        x = torch.randn(b * t, c, h, w, generator=g)
+        gy = torch.randn(b * t, c, h, w, generator=g)
+        y_out = RS.TemporalShift.shift(x.clone(), t, fold_div=8, inplace=False)
+        xin = x.clone().requires_grad_(True)
+        x_alias = xin * 1.0            # non-leaf so that the in-place Function may write into it
+        y_in = RS.TemporalShift.shift(x_alias, t, fold_div=8, inplace=True)
+        aliased = bool((x_alias.detach() == y_in.detach()).all())
+        y_in.backward(gy.clone())
+        save(f"tsm_c{c}", x=x, gy=gy, y=y_out, y_inplace=y_in, gx=xin.grad, T=t, aliased=aliased)
+
+
+def _fill(mod, g, scale=0.3):
+    with torch.no_grad():
+        for p in mod.parameters():
+            if p.requires_grad:
+                p.copy_(torch.randn(p.shape, generator=g) * scale / max(1.0, p.shape[-1] ** 0.5) * 4)
+
+
+def gen_heads():
+    g = torch.Generator().manual_seed(21)
+    for L in (1, 3):
+        m = RM.GRUPrediction(48, 7, 48, num_layers=L)
+        _fill(m, g)
+        m.eval()
+        x = torch.randn(3, 6, 48, generator=g, requires_grad=True)
+        y = m(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        arrs = {"x": x, "y": y, "gy": gy, "gx": x.grad}
+        for k, v in m.state_dict().items():
+            arrs["p." + k] = v
+        for k, v in m.named_parameters():
+            arrs["g." + k] = v.grad
+        save(f"gru_L{L}", **arrs)
+    # location head: Sequential(MLP(h, 3h, h, 2), Linear(h, 2))  (train_e2e_spatial.py:402-410)
+    hd = 32
+    loc = nn.Sequential(RC.MLP(hd, hd * 3, output_dim=hd, num_layers=2), nn.Linear(hd, 2))
+    _fill(loc, g)
+    x = torch.randn(2, 5, hd, generator=g, requires_grad=True)
+    y = loc(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    arrs = {"x": x, "y": y, "gy": gy, "gx": x.grad}
+    for k, v in loc.state_dict().items():
+        arrs["p." + k] = v
+    for k, v in loc.named_parameters():
+        arrs["g." + k] = v.grad
+    save("loc_mlp", **arrs)
+    # minGRU predictor
+    m = RG.MinRNNPredictor(input_size=24, hidden_size=40, output_size=7, n_layers=3, rnn_type="mingru")
+    _fill(m, g)
+    x = torch.randn(2, 9, 24, generator=g, requires_grad=True)
+    y = m(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    arrs = {"x": x, "y": y, "gy": gy, "gx": x.grad}
+    for k, v in m.state_dict().items():
+        arrs["p." + k] = v
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            arrs["g." + k] = v.grad
+    save("mingru", **arrs)
+
+
+def gen_step():
+    """One reference step(): weighted CE + masked L1 (train_e2e_spatial.py:566-593),
+    AdamW with per-tensor groups and `_pred_loc` at lr/5 (model/common.py:32-42,61-75)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(31)
+
+    class Heads(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._pred_fine = RM.GRUPrediction(32, 7, 32, 1)
+            self._pred_loc = nn.Sequential(RC.MLP(32, 96, output_dim=32, num_layers=2), nn.Linear(32, 2))
+
+    m = Heads()
+    _fill(m, g)
+    m.eval()  # dropout off so that the step is deterministic
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    class Holder(RC.BaseRGBModel):
+        device = "cpu"
+
+    hold = Holder()
+    hold._model = m
+    opt, scaler = hold.get_optimizer({"lr": 1e-2})
+    assert scaler is None
+    x = torch.randn(2, 8, 32, generator=g)
+    label = torch.randint(0, 7, (2, 8), generator=g)
+    label[0, :3] = 0
+    xy = torch.rand(2, 8, 2, generator=g)
+    losses = []
+    for _ in range(2):
+        pred = m._pred_fine(x)
+        loc = m._pred_loc(x)
+        w = torch.FloatTensor([1] + [5] * 6)
+        lab = label.flatten()
+        loss_cls = F.cross_entropy(pred.reshape(-1, 7), lab, weight=w)
+        mask = (lab != 0).float().reshape(-1)
+        xy_loss = F.l1_loss(loc.reshape(-1, 2).sigmoid(), xy.reshape(-1, 2), reduction="none").sum(dim=-1)
+        loss_loc = (xy_loss * mask).sum() / (mask.sum() + 1e-6)
+        loss = loss_cls + loss_loc
+        RC.step(opt, None, loss)
+        losses.append([loss.item(), loss_cls.item(), loss_loc.item()])
+    arrs = {"x": x, "label": label, "xy": xy, "losses": np.array(losses, np.float64), "lr": 1e-2}
+    for k, v in sd0.items():
+        arrs["p0." + k] = v
+    for k, v in m.state_dict().items():
+        arrs["p2." + k] = v
+    save("step_heads", **arrs)
+
+
+def gen_postproc():
+    rng = np.random.RandomState(5)
+    classes = ["serve", "receive", "set", "attack", "block", "score"]
+    n = 300
+    scores = rng.dirichlet(np.ones(7) * 0.3, size=n).astype(np.float32)
+    locs = rng.rand(n, 2).astype(np.float32)
+    pred = np.argmax(scores, 1)
+    events = [{"label": classes[pred[i] - 1], "frame": i, "score": scores[i, pred[i]].item(), "xy": locs[i].tolist()}
+              for i in range(n) if pred[i] != 0]
+    data = [{"video": "v", "events": events}]
+    f = RSC.filter_events_by_score(data, fg_threshold=0.15)
+    import copy
+    s = RSC.non_max_suppression_events(copy.deepcopy(f), 3)
+    lab2i = {c: i for i, c in enumerate(classes)}
+    enc = lambda evs: np.array([[e["frame"], lab2i[e["label"]]] for e in evs], np.int64).reshape(-1, 2)
+    save("postproc", scores=scores, locs=locs, filtered=enc(f[0]["events"]), nms=enc(s[0]["events"]),
+         nms_scores=np.array([e["score"] for e in s[0]["events"]], np.float64))
+
+
+class _RefComposite(nn.Module):
+    """The reference's forward (train_e2e_spatial.py:416-455) over: oracle RegNet-Y with the
+    REFERENCE's make_temporal_shift/GatedShift/_GSM inserted, reference GRUPrediction and
+    reference location MLP."""
+
+    def __init__(self, feature_arch, temporal_arch, clip_len, num_classes=7):
+        super().__init__()
+        base, kind = feature_arch.rsplit("_", 1)
+        feats = O.RegNetY({"rny002": "regnety_002", "rny008": "regnety_008"}[base])
+        fd = feats.head.fc.in_features
+        feats.head.fc = nn.Identity()
+        RS.make_temporal_shift(feats, clip_len, is_gsm=(kind == "gsm"))
+        self._features = feats
+        hd = min(fd, 768)
+        if temporal_arch == "mingru":
+            self._pred_fine = RG.MinRNNPredictor(input_size=fd, hidden_size=hd, output_size=num_classes,
+                                                 n_layers=3, rnn_type="mingru", batch_first=True)
+        else:
+            self._pred_fine = RM.GRUPrediction(fd, num_classes, hd, num_layers=3 if temporal_arch[0] == "d" else 1)
+        self._pred_loc = nn.Sequential(RC.MLP(hd, hd * 3, output_dim=hd, num_layers=2), nn.Linear(hd, 2))
+        self._fd = fd
+
+    def forward(self, x):
+        b, t, c, h, w = x.shape
+        im = self._features(x.view(-1, c, h, w)).reshape(b, t, self._fd)
+        return {"im_feat": self._pred_fine(im), "loc_feat": self._pred_loc(im), "cnn_feat": im}
+
+
+def gen_full():
+    import torch.nn.functional as F
+    for arch, tarch, tag in (("rny008_gsm", "gru", "full_rny008_gsm_gru"), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru")):
+        torch.manual_seed(0)
+        m = _RefComposite(arch, tarch, clip_len=4)
+        O.randomize_(m, seed=3)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(2, 4, 3, 64, 64, generator=g)
+        label = torch.randint(0, 7, (2, 4), generator=g)
+        xy = torch.rand(2, 4, 2, generator=g)
+        arrs = {"x": x, "label": label, "xy": xy,
+                "param_abs_sum": float(sum(p.abs().sum().item() for p in m.parameters()))}
+        m.eval()
+        with torch.no_grad():
+            d = m(x)
+        for k, v in d.items():
+            arrs["eval." + k] = v
+        if tarch == "gru":
+            m.train()
+            m._pred_fine._dropout.p = 0.0          # dropout RNG cannot be matched; keep the rest of train mode
+            d = m(x)
+            for k, v in d.items():
+                arrs["train." + k] = v
+            lab = label.flatten()
+            w = torch.FloatTensor([1] + [5] * 6)
+            loss_cls = F.cross_entropy(d["im_feat"].reshape(-1, 7), lab, weight=w)
+            mask = (lab != 0).float()
+            l1 = F.l1_loss(d["loc_feat"].reshape(-1, 2).sigmoid(), xy.reshape(-1, 2), reduction="none").sum(-1)
+            loss_loc = (l1 * mask).sum() / (mask.sum() + 1e-6)
+            (loss_cls + loss_loc).backward()
+            arrs["loss"] = np.array([loss_cls.item(), loss_loc.item()], np.float64)
+            names, norms = [], []
+            for n, p in m.named_parameters():
+                if p.grad is None:
+                    continue
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+                if ("conv3D" in n or n.endswith("gsm.bn.weight") or n.startswith("_features.stem")
+                        or n.startswith("_features.s4.b2.se") or n.startswith("_features.s1.b1.conv2")):
+                    arrs["g." + n] = p.grad
+            arrs["grad_names"] = np.array(names)
+            arrs["grad_norms"] = np.array(norms, np.float64)
+            for n, bf in m.named_buffers():
+                if n.endswith("running_mean") and ("s1.b1" in n or "stem" in n):
+                    arrs["buf." + n] = bf
+        save(tag, **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    gen_gsm()
+    gen_gated_shift()
+    gen_tsm()
+    gen_heads()
+    gen_step()
+    gen_postproc()
+    gen_full()
