@@ -1,0 +1,50 @@
+// Shared device helpers for the STES gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/stes.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define STES_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float f) { return (bf16)f; }
+
+// 8 bf16 (16 bytes) <-> 8 floats
+__device__ __forceinline__ void unpack8(const bf16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    return v;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Error plumbing shared by every entry point (defined in stes_api.hip).
+int stes_set_error(int code, const char* msg);
+#define STES_CHECK(cond, code, msg) \
+    do { if (!(cond)) return stes_set_error((code), (msg)); } while (0)
+#define STES_LAUNCH_CHECK() \
+    do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return stes_set_error(STES_ERR_LAUNCH, hipGetErrorString(e_)); } while (0)
+
+static inline int stes_div_up(long a, long b) { return (int)((a + b - 1) / b); }

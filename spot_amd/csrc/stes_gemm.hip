@@ -1,0 +1,451 @@
+// bf16 MFMA GEMMs for the 1x1 convolutions and Linear layers of the STES path.
+//
+// stes_gemm : C[M,N] = act(pro(A) W^T + bias), tall-and-skinny (M = frames*H*W is huge, K and N
+//             are channel counts).  128 x BN output tile per workgroup pass, 4 waves (2x2), BK = 32,
+//             register-staged double-buffered LDS.  The BatchNorm-apply/ReLU/SE-gate "prologue" runs
+//             on A between the global load and the LDS store, so the normalised activations of the
+//             previous layer are never written to HBM; BatchNorm batch statistics of the output are
+//             reduced in registers over every M tile the workgroup walks and leave as one atomic per
+//             column per workgroup.
+// stes_wgrad: dW[N1,N2] += P^T pro(Q); the reduction runs over the rows, so both operands are
+//             consumed transposed: tiles land in LDS row-major and are fetched with
+//             ds_read_b64_tr_b16 straight into MFMA fragment order.
+#include "stes_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+
+// 16-byte chunk swizzle for [rows][32] bf16 tiles (64-byte rows): chunk' = chunk ^ SWZ[(row>>2)&3]
+// makes every ds_read_b128 lane group of the MFMA fragment read hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int swz(int row, int chunk) {
+    const int g = (row >> 2) & 3;
+    return chunk ^ ((4 - g) & 3);      // g = 0,1,2,3 -> 0,3,2,1
+}
+
+struct RowInfo {
+    const bf16* a;       // main source row pointer (nullptr: row out of range -> zeros)
+    const bf16* a0;      // compact source row pointer
+    const float* gate;   // gate row pointer
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots) {
+    constexpr int NI = BN / 32;          // 16-wide n fragments per wave (wave covers BN/2 columns)
+    constexpr int BLOADS = BN / 64;      // W-tile chunk loads per thread
+    __shared__ __attribute__((aligned(16))) bf16 As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) bf16 Bs[2][BN * BK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // block -> (n tile, m slot); the n tiles of one m slot share blockIdx % 8 (one XCD's L2).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nt = idx % n_tiles;
+    const int slot = (idx / n_tiles) * 8 + xcd;
+    if (slot >= m_slots) return;
+    const int n0 = nt * BN;
+
+    const bf16* __restrict__ A = (const bf16*)p.A;
+    const bf16* __restrict__ A0 = (const bf16*)p.A0;
+    const bf16* __restrict__ W = (const bf16*)p.W;
+    const int K = p.K, N = p.N;
+    const long M = p.M;
+    const int nk = (K + BK - 1) / BK;
+    const bool has_affine = p.a_scale != nullptr;
+    const bool has_gate = p.a_gate != nullptr;
+    const bool pro = has_affine || has_gate;
+
+    const int ld_chunk = tid & 3, ld_row = tid >> 2;   // A/W tile loader coordinates
+
+    float csum[NI][4], csq[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { csum[i][r] = 0.f; csq[i][r] = 0.f; }
+    const bool stats = p.col_sum != nullptr;
+
+    for (int mt = slot; mt < m_tiles; mt += m_slots) {
+        const long m0 = (long)mt * BM;
+        RowInfo ri[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long m = m0 + ld_row + h * 64;
+            ri[h].a = nullptr; ri[h].a0 = nullptr; ri[h].gate = nullptr;
+            if (m < M) {
+                long src = m;
+                if (p.map_stride > 1) {
+                    const long hw = (long)p.Ho * p.Wo;
+                    const long n = m / hw; const int rem = (int)(m - n * hw);
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    src = (n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                }
+                ri[h].a = A + src * p.lda;
+                if (A0) ri[h].a0 = A0 + src * p.lda0;
+                if (has_gate) ri[h].gate = p.a_gate + (m / p.gate_group) * (long)K;
+            }
+        }
+        const bf16* wrow[BLOADS];
+#pragma unroll
+        for (int h = 0; h < BLOADS; ++h) {
+            const int n = n0 + ld_row + h * 64;
+            wrow[h] = (n < N) ? W + (long)n * p.ldw : nullptr;
+        }
+
+        f32x4 acc[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        bf16x8 ra[2], rb[BLOADS];
+        auto gload = [&](int ks) {
+            const int k = ks * BK + ld_chunk * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (ri[h].a != nullptr && k < K) {
+                    const bf16* src = (k < p.k0) ? ri[h].a0 + k : ri[h].a + k;
+                    ra[h] = *reinterpret_cast<const bf16x8*>(src);
+                } else {
+                    ra[h] = zero8();
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < BLOADS; ++h)
+                rb[h] = (wrow[h] != nullptr && k < K) ? *reinterpret_cast<const bf16x8*>(wrow[h] + k) : zero8();
+        };
+        auto lstore = [&](int ks, int buf) {
+            const int k = ks * BK + ld_chunk * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 v = ra[h];
+                if (pro && ri[h].a != nullptr && k < K) {
+                    float f[8];
+                    unpack8(v, f);
+                    if (has_affine) {
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.a_scale + k);
+                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.a_scale + k + 4);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.a_shift + k);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.a_shift + k + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { f[i] = f[i] * s0[i] + b0[i]; f[i + 4] = f[i + 4] * s1[i] + b1[i]; }
+                        if (p.a_relu) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f);
+                        }
+                    }
+                    if (has_gate) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ri[h].gate + k);
+                        const f32x4 g1 = *reinterpret_cast<const f32x4*>(ri[h].gate + k + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { f[i] *= g0[i]; f[i + 4] *= g1[i]; }
+                    }
+                    v = pack8(f);
+                }
+                const int row = ld_row + h * 64;
+                *reinterpret_cast<bf16x8*>(&As[buf][row * BK + swz(row, ld_chunk) * 8]) = v;
+            }
+#pragma unroll
+            for (int h = 0; h < BLOADS; ++h) {
+                const int row = ld_row + h * 64;
+                *reinterpret_cast<bf16x8*>(&Bs[buf][row * BK + swz(row, ld_chunk) * 8]) = rb[h];
+            }
+        };
+
+        gload(0);
+        lstore(0, 0);
+        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < nk) gload(ks + 1);
+            bf16x8 fa[NI], fb[4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = wn * (BN / 2) + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(&Bs[buf][row * BK + swz(row, fq) * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const bf16x8*>(&As[buf][row * BK + swz(row, fq) * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < nk) lstore(ks + 1, buf ^ 1);
+            __syncthreads();
+        }
+
+        // epilogue: lane holds, per (i, j), columns n = n0 + wn*BN/2 + i*16 + fq*4 + r of row m = m0 + wm*64 + j*16 + fr
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int nb = n0 + wn * (BN / 2) + i * 16 + fq * 4;
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < N) bias[r] = p.bias[nb + r];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long m = m0 + wm * 64 + j * 16 + fr;
+                if (m >= M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] + bias[r];
+                    if (p.act == 1) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (p.c_f32) {
+                    float* c = (float*)p.C + m * p.ldc + nb;
+                    if (nb + 3 < N && (p.ldc & 3) == 0) {
+                        *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (nb + r < N) c[r] = v[r];
+                    }
+                } else {
+                    bf16* c = (bf16*)p.C + m * p.ldc + nb;
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o[r] = (bf16)v[r]; v[r] = (float)o[r]; }
+                    if (nb + 3 < N && (p.ldc & 3) == 0) {
+                        *reinterpret_cast<bf16x4*>(c) = o;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (nb + r < N) c[r] = o[r];
+                    }
+                }
+                if (stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { csum[i][r] += v[r]; csq[i][r] += v[r] * v[r]; }
+                }
+            }
+        }
+    }
+
+    if (stats) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = csum[i][r], q = csq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                const int n = n0 + wn * (BN / 2) + i * 16 + fq * 4 + r;
+                if (fr == 0 && n < N) { atomicAdd(p.col_sum + n, s); atomicAdd(p.col_sumsq + n, q); }
+            }
+    }
+}
+
+// ------------------------------------------------------------------ wgrad
+constexpr int WK = 32;                       // rows (reduction) per step
+__device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
+    return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+}
+
+template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
+__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk) {
+    constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
+    constexpr int FI = T / 32;               // 16-wide fragments per wave per operand
+    constexpr int CH = T / 8;                // 16-byte chunks per tile row
+    constexpr int LOADS = (WK * CH) / 256;   // chunk loads per thread per operand (2 or 1)
+    __shared__ __attribute__((aligned(16))) bf16 Ps[2][WK * LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Qs[2][WK * LDT];
+    __shared__ float bias_acc[T];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w1 = wave >> 1, w2 = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n1_0 = blockIdx.y * T, n2_0 = blockIdx.z * T;
+    const long m_begin = (long)blockIdx.x * m_chunk;
+    const long m_end = (m_begin + m_chunk < p.M) ? m_begin + m_chunk : p.M;
+    if (m_begin >= m_end) return;
+
+    const bf16* __restrict__ P = (const bf16*)p.P;
+    const bf16* __restrict__ Q = (const bf16*)p.Q;
+    const bf16* __restrict__ Q0 = (const bf16*)p.Q0;
+    const bool has_affine = p.q_scale != nullptr, has_gate = p.q_gate != nullptr;
+    const bool do_bias = p.dbias != nullptr && blockIdx.z == 0;
+    if (do_bias && tid < T) bias_acc[tid] = 0.f;
+
+    const int lc = tid % CH, lr = tid / CH;          // loader: chunk, row (row step 256/CH)
+    constexpr int RSTEP = 256 / CH;
+    const int c1 = n1_0 + lc * 8, c2 = n2_0 + lc * 8;
+    const bool c1_ok = c1 < p.N1, c2_ok = c2 < p.N2;
+
+    f32x4 acc[FI][FI];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+    bf16x8 rp[LOADS], rq[LOADS];
+    long qm[LOADS];   // logical row of each staged q chunk (for the gate lookup)
+    auto gload = [&](long mb) {
+#pragma unroll
+        for (int h = 0; h < LOADS; ++h) {
+            const long m = mb + lr + h * RSTEP;
+            qm[h] = m;
+            if (m < m_end) {
+                rp[h] = c1_ok ? *reinterpret_cast<const bf16x8*>(P + m * p.ldp + c1) : zero8();
+                long src = m;
+                if (p.map_stride > 1) {
+                    const long hw = (long)p.Ho * p.Wo;
+                    const long n = m / hw; const int rem = (int)(m - n * hw);
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    src = (n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                }
+                if (c2_ok) rq[h] = (c2 < p.k0) ? *reinterpret_cast<const bf16x8*>(Q0 + src * p.ldq0 + c2)
+                                               : *reinterpret_cast<const bf16x8*>(Q + src * p.ldq + c2);
+                else rq[h] = zero8();
+            } else {
+                rp[h] = zero8(); rq[h] = zero8();
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < LOADS; ++h) {
+            const int row = lr + h * RSTEP;
+            bf16x8 v = rq[h];
+            if ((has_affine || has_gate) && qm[h] < m_end && c2_ok) {
+                float f[8];
+                unpack8(v, f);
+                if (has_affine) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f[i] = f[i] * p.q_scale[c2 + i] + p.q_shift[c2 + i];
+                        if (p.q_relu) f[i] = fmaxf(f[i], 0.f);
+                    }
+                }
+                if (has_gate) {
+                    const float* g = p.q_gate + (qm[h] / p.gate_group) * (long)p.N2 + c2;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] *= g[i];
+                }
+                v = pack8(f);
+            }
+            *reinterpret_cast<bf16x8*>(&Qs[buf][rho(row) * LDT + lc * 8]) = v;
+            *reinterpret_cast<bf16x8*>(&Ps[buf][rho(row) * LDT + lc * 8]) = rp[h];
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum[i] += (float)rp[h][i];
+            }
+        }
+    };
+
+    gload(m_begin);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (long mb = m_begin; mb < m_end; mb += WK) {
+        const bool more = mb + WK < m_end;
+        if (more) gload(mb + WK);
+        bf16x8 fa[FI], fb[FI];
+        // transposed fragment reads: lane supplies row 8*fq + (fr>>2) (+4), columns 4*(fr&3)..+3
+        const int r_lo = rho(8 * fq + (fr >> 2)), r_hi = rho(8 * fq + (fr >> 2) + 4);
+        const int cc = 4 * (fr & 3);
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int col = w1 * (T / 2) + i * 16 + cc;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(&Ps[buf][r_lo * LDT + col]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(&Ps[buf][r_hi * LDT + col]));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < FI; ++j) {
+            const int col = w2 * (T / 2) + j * 16 + cc;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(&Qs[buf][r_lo * LDT + col]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(&Qs[buf][r_hi * LDT + col]));
+            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // D[row = n1 (fq*4 + r)][col = n2 (fr)]
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) {
+            const int n2 = n2_0 + w2 * (T / 2) + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + w1 * (T / 2) + i * 16 + fq * 4 + r;
+                if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.dW + (long)n1 * p.lddw + n2, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&bias_acc[lc * 8 + i], bsum[i]);
+        __syncthreads();
+        if (tid < T && n1_0 + tid < p.N1) atomicAdd(p.dbias + n1_0 + tid, bias_acc[tid]);
+    }
+}
+
+}  // namespace
+
+extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
+    STES_CHECK(a && a->A && a->W && a->C, STES_ERR_ARG, "stes_gemm: null pointer");
+    STES_CHECK(a->M > 0 && a->N > 0 && a->K > 0, STES_ERR_ARG, "stes_gemm: empty shape");
+    STES_CHECK(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0, STES_ERR_ARG, "stes_gemm: K, lda, ldw must be multiples of 8");
+    STES_CHECK(a->k0 == 0 || (a->A0 && a->k0 % 8 == 0 && a->lda0 % 8 == 0 && a->k0 <= a->K), STES_ERR_ARG, "stes_gemm: bad compact source");
+    STES_CHECK((a->a_scale == nullptr) == (a->a_shift == nullptr), STES_ERR_ARG, "stes_gemm: scale/shift must come together");
+    STES_CHECK(!a->a_gate || a->gate_group > 0, STES_ERR_ARG, "stes_gemm: gate_group");
+    STES_CHECK(a->map_stride <= 1 || (a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0), STES_ERR_ARG, "stes_gemm: row map dims");
+    STES_CHECK((a->col_sum == nullptr) == (a->col_sumsq == nullptr), STES_ERR_ARG, "stes_gemm: stats pointers");
+    STES_CHECK(!(a->col_sum && a->c_f32), STES_ERR_ARG, "stes_gemm: stats need bf16 output");
+    const int m_tiles = stes_div_up(a->M, BM);
+    const bool wide = a->N > 64;
+    const int bn = wide ? 128 : 64;
+    const int n_tiles = stes_div_up(a->N, bn);
+    int m_slots = m_tiles;
+    const int cap = 2048 / n_tiles > 8 ? 2048 / n_tiles : 8;
+    if (m_slots > cap) m_slots = cap;
+    const int slot_groups = stes_div_up(m_slots, 8);
+    const int grid = slot_groups * n_tiles * 8;
+    if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots);
+    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
+    STES_CHECK(a && a->P && a->Q && a->dW, STES_ERR_ARG, "stes_wgrad: null pointer");
+    STES_CHECK(a->M > 0 && a->N1 > 0 && a->N2 > 0, STES_ERR_ARG, "stes_wgrad: empty shape");
+    STES_CHECK(a->N2 % 8 == 0 && a->ldp % 8 == 0 && a->ldq % 8 == 0, STES_ERR_ARG, "stes_wgrad: N2, ldp, ldq must be multiples of 8");
+    STES_CHECK(a->k0 == 0 || (a->Q0 && a->k0 % 8 == 0 && a->ldq0 % 8 == 0), STES_ERR_ARG, "stes_wgrad: bad compact source");
+    STES_CHECK(a->ldp >= (a->N1 + 7) / 8 * 8, STES_ERR_ARG, "stes_wgrad: ldp must cover N1 rounded up to 8 (pad the operand)");
+    const bool big = a->N1 > 64 && a->N2 > 64;
+    const int t = big ? 128 : 64;
+    const int t1 = stes_div_up(a->N1, t), t2 = stes_div_up(a->N2, t);
+    // split the rows so that the grid has ~1024 workgroups, at least 256 rows each
+    long want = 1024 / (t1 * t2);
+    if (want < 1) want = 1;
+    long chunk = (a->M + want - 1) / want;
+    if (chunk < 256) chunk = 256;
+    chunk = (chunk + WK - 1) / WK * WK;
+    const int mb = stes_div_up(a->M, chunk);
+    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk);
+    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}

@@ -1,0 +1,69 @@
+"""stes_gemm / stes_wgrad against fp32 torch on bf16-exact inputs (GPU)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(*shape, g, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (300, 128, 64), (1000, 320, 128), (77, 7, 1536), (513, 768, 320), (256, 2304, 768)])
+def test_gemm_plain(M, N, K):
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    for out_dtype in (torch.bfloat16, torch.float32):
+        C = torch.full((M, N), 7.0, dtype=out_dtype, device="cuda")
+        lib.gemm(A.cuda(), W.cuda(), C, M, N, K, bias=bias.cuda())
+        torch.cuda.synchronize()
+        tol = 2e-2 if out_dtype == torch.bfloat16 else 2e-3
+        torch.testing.assert_close(C.float().cpu(), ref, rtol=tol, atol=tol)
+
+
+def test_gemm_prologue_stats_compact_and_rowmap():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(5)
+    n_img, Hi, Wi, K, N, fold = 3, 6, 8, 64, 128, 16
+    Ho, Wo = Hi // 2, Wi // 2
+    X = _bf(n_img * Hi * Wi, K, g=g)
+    G = _bf(n_img * Hi * Wi, fold, g=g)
+    W = _bf(N, K, g=g, scale=K ** -0.5)
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    gate = torch.rand(n_img, K, generator=g)
+    # reference: rows of the stride-2 sampled image, first `fold` columns from G
+    full = torch.cat([G.float(), X.float()[:, fold:]], 1).view(n_img, Hi, Wi, K)[:, ::2, ::2].reshape(-1, K)
+    a = torch.relu(full * scale + shift)
+    a = (a.view(n_img, Ho * Wo, K) * gate[:, None]).reshape(-1, K).to(torch.bfloat16).float()
+    ref = a @ W.float().t()
+    M = n_img * Ho * Wo
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    s1 = torch.zeros(N, device="cuda"); s2 = torch.zeros(N, device="cuda")
+    lib.gemm(X.cuda(), W.cuda(), C, M, N, K, A0=G.cuda(), lda0=fold, k0=fold, scale=scale.cuda(), shift=shift.cuda(),
+             relu=True, gate=gate.cuda(), gate_group=Ho * Wo, rowmap=(2, Ho, Wo, Hi, Wi), stats=(s1, s2))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(C.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    cb = C.float().cpu()
+    torch.testing.assert_close(s1.cpu(), cb.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(s2.cpu(), (cb * cb).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(256, 64, 32), (1000, 128, 64), (4099, 320, 320), (2048, 768, 768), (500, 7, 1536), (3000, 64, 64)])
+def test_wgrad(M, N1, N2):
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(M + N1)
+    ldp = (N1 + 7) // 8 * 8
+    P = torch.zeros(M, ldp, dtype=torch.bfloat16)
+    P[:, :N1] = _bf(M, N1, g=g)
+    Q = _bf(M, N2, g=g)
+    scale, shift = torch.rand(N2, generator=g) + 0.5, torch.randn(N2, generator=g) * 0.3
+    q = torch.relu(Q.float() * scale + shift).to(torch.bfloat16).float()
+    ref = P[:, :N1].float().t() @ q
+    dW = torch.zeros(N1, N2, device="cuda"); db = torch.zeros(N1, device="cuda")
+    lib.wgrad(P.cuda(), Q.cuda(), dW, M, N1, N2, ldp=ldp, scale=scale.cuda(), shift=shift.cuda(), relu=True, dbias=db)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dW.cpu(), ref, rtol=2e-3, atol=2e-3 * M ** 0.5)
+    torch.testing.assert_close(db.cpu(), P[:, :N1].float().sum(0), rtol=1e-3, atol=1e-2)
