@@ -49,6 +49,7 @@ typedef struct {
     const float* bias;  int32_t act;          /* 0 none, 1 relu */
     void* C; int64_t ldc; int32_t c_f32;      /* output bf16 (0) or f32 (1) */
     float* col_sum; float* col_sumsq;
+    const uint16_t* relu_mask; int64_t ldmask; /* optional: C[m,n] = 0 where relu_mask[m,n] <= 0 (ReLU backward) */
     int64_t M; int32_t N; int32_t K;
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
@@ -68,6 +69,147 @@ typedef struct {
     int64_t M; int32_t N1; int32_t N2;
 } stes_wgrad_args;
 int stes_wgrad(const stes_wgrad_args* a, void* stream);
+
+/* ---------------------------------------------------- BatchNorm / block glue ----
+ * Training-mode BatchNorm2d/3d is split around the convolutions: the producing kernel
+ * accumulates per-channel sum / sum of squares, stes_bn_finalize turns them into
+ * scale = gamma*invstd, shift = beta - mean*scale (and updates the running statistics with
+ * the unbiased variance, momentum as torch.nn.BatchNorm), and the consuming kernel applies
+ * scale/shift(+ReLU) while it loads.  training = 0 uses the running statistics instead.
+ * Replaces: timm BatchNormAct2d inside every ConvNormAct of regnety_008 and nn.BatchNorm3d of
+ * _GSM (model/shift.py:94,108).                                                         */
+int stes_bn_finalize(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int training,
+                     float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
+
+/* out = relu(scale*c + shift + r), r = res_scale*res + res_shift | res | 0; optional sum / sum of
+ * squares of out's first stat_c channels (the next block's gated-shift BatchNorm3d input).
+ * Replaces: conv3.bn + shortcut add + act3 of the timm Bottleneck, and stem bn + ReLU.   */
+int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
+                         const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
+                         float* stat_sumsq, int stat_c, int64_t M, int C, void* stream);
+
+/* out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1), act = relu(scale*c+shift)
+ * when scale is given.  Squeeze of timm SEModule, its backward, and the head's global pool.   */
+int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, const uint16_t* mul, float* out,
+                   uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream);
+
+/* timm SEModule excite: hidden = relu(w1 pooled + b1); gate = sigmoid(w2 hidden + b2). */
+int stes_se_fc(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+               float* hidden, float* gate, int N, int C, int R, void* stream);
+int stes_se_fc_bwd(const float* dgate_raw, const float* gate, const float* hidden, const float* w1, const float* w2,
+                   float* dpre2, float* dpre1, float* dpool, float inv_hw, int N, int C, int R, void* stream);
+/* dW[n1,n2] += P[N,n1]^T Q[N,n2], db[n1] += colsum(P): fp32 weight gradients of the SE FCs. */
+int stes_f32_outer(const float* P, const float* Q, float* dW, float* db, int N, int n1, int n2, void* stream);
+
+/* BatchNorm backward.  The incoming gradient is formed on the fly:
+ *   dY = (D * mul[m/group] + add[m/group]) * [act_scale*act_raw + act_shift > 0]
+ * (each factor optional).  reduce: s_dy += sum dY, s_dyr1 += sum dY*raw1, s_dyr2 += sum dY*raw2.
+ * finalize: alpha/beta/delta such that d(raw) = alpha*dY + beta*raw + delta, and
+ * dgamma += sum dY*xhat, dbeta += sum dY.  apply: out = alpha*dY + beta*raw1 + delta.     */
+typedef struct {
+    const uint16_t* D; const float* mul; const float* add; int32_t group;
+    const uint16_t* act_raw; const float* act_scale; const float* act_shift;
+    const uint16_t* raw1; const uint16_t* raw2;
+    float* s_dy; float* s_dyr1; float* s_dyr2;
+    const float* alpha; const float* beta; const float* delta; uint16_t* out;
+    int64_t M; int32_t C;
+} stes_bn_bwd_args;
+int stes_bn_bwd_reduce(const stes_bn_bwd_args* a, void* stream);
+int stes_bn_bwd_finalize(const float* s_dy, const float* s_dyr, const float* mean, const float* invstd,
+                         const float* gamma, double count, float* alpha, float* beta, float* delta,
+                         float* dgamma, float* dbeta, int C, void* stream);
+int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream);
+
+/* Gradient w.r.t. a bottleneck's input: out = ((c<fold ? dXf : dY) + residual) * (X > 0); the
+ * residual is either same-shape (identity shortcut) or the stride-s shortcut conv's input
+ * gradient given at output resolution and scattered to the even pixels.                  */
+int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
+                       int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
+                       int64_t M, int C, void* stream);
+/* Backward of global average pooling + the last block's ReLU: dZ = (da+db)/HW * (out>0). */
+int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_t* dZ, int N, int HW, int C, void* stream);
+
+/* ---------------------------------------------------- grouped 3x3 convolution ----
+ * timm regnety_008 conv2: 3x3, padding 1, stride 1|2, groups = C/16, no bias.  in/out NHWC bf16.
+ * Weights are re-packed from the checkpoint layout [C][16][3][3] fp32 into MFMA fragment order
+ * by stes_pack_conv3x3g (one buffer for forward, one for the input gradient; G*5*512 bf16 each).
+ * forward applies relu(in_scale*x + in_shift) (the previous BatchNorm+ReLU) while loading and
+ * accumulates the output's per-channel sum / sum of squares.                              */
+int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int G, void* stream);
+int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
+                      const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
+                      int stride, int C, void* stream);
+int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, int N, int Hi, int Wi, int Ho,
+                        int Wo, int stride, int C, void* stream);
+/* dw [C][16][3][3] fp32 += (atomics; caller zeroes) */
+int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, const float* in_scale, const float* in_shift, float* dw,
+                        int N, int Hi, int Wi, int Ho, int Wo, int stride, int C, void* stream);
+/* Stem 3x3 stride-2 conv as im2col + stes_gemm: x NCHW fp32 -> patches [N*Ho*Wo][32] bf16,
+ * column k = ci*9 + kh*3 + kw (timm stem.conv weight order), columns >= 9*Cin zero.       */
+int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, int W, void* stream);
+
+/* ---------------------------------------------------- temporal shift ----
+ * Gated Shift Module, reference model/shift.py:83-161 (_GSM.forward :103-130, GatedShift.forward
+ * :157-161).  X is the block input [B*T*H*W][ldx] NHWC bf16; the module acts on channels [0,fold).
+ *   stes_gsm_gate : gate[m,2] = tanh(conv3D(relu(scale*x+shift)))   (scale/shift = BatchNorm3d, from
+ *                   stes_bn_finalize; conv3D weight [2][fold/2][3][3][3], bias [2], fp32)
+ *   stes_gsm_shift: G[m, dest(c)] = y[t+1|t-1] + (x - y), y = gate*x; G is compact [M][fold]
+ * and the backward pieces (dG is read with row stride ldg, destination-channel order):
+ *   stes_gsm_bwd_gate    : dpre[m,2], gradient at the conv3D output (before tanh')
+ *   stes_gsm_bwd_wgrad   : dw [2][fold/2][27], db [2]  += (atomics)
+ *   stes_gsm_bwd_bnreduce: BatchNorm3d backward sums, s_dy += sum d, s_dyx += sum d*x
+ *   stes_gsm_bwd_dx      : dXf[m][fold] = shift path + gate path + BatchNorm3d path         */
+typedef struct { int32_t B, T, H, W, ldx, fold; } stes_gsm_geom;
+int stes_gsm_gate(const uint16_t* X, const float* scale, const float* shift, const float* w3d, const float* b3d,
+                  float* gate, const stes_gsm_geom* g, void* stream);
+int stes_gsm_shift(const uint16_t* X, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_gate(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, float* dpre,
+                      const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* X, const float* scale, const float* shift, float* dw,
+                       float* db, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_bnreduce(const float* dpre, const uint16_t* X, const float* scale, const float* shift, const float* w3d,
+                          float* s_dy, float* s_dyx, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_dx(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, const float* dpre,
+                    const float* scale, const float* shift, const float* w3d, const float* alpha, const float* beta,
+                    const float* delta, uint16_t* dXf, const stes_gsm_geom* g, void* stream);
+/* per-column sum / sum of squares of X[:, :ncols] (atomics) */
+int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, void* stream);
+/* TemporalShift.shift, reference model/shift.py:37-52 (out of place; backward = adjoint shift). */
+int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C, int B, int T, int H, int W, int backward, void* stream);
+
+/* ---------------------------------------------------- temporal head, loss, optimiser ----
+ * Bidirectional GRU layer (torch.nn.GRU inside GRUPrediction, reference model/modules.py:20-36).
+ * gi = x W_ih^T + b_ih for both directions comes from stes_gemm ([B,T,2,3H] bf16).  forward runs
+ * T launches; with `saved` != NULL it keeps what the backward needs.  backward runs T launches
+ * and leaves dgi (for dW_ih, db_ih, dx) and dgh (for dW_hh, db_hh with hprev_bf).            */
+typedef struct {
+    const uint16_t* gi; const uint16_t* whh; const uint16_t* whhT; const float* bhh;
+    uint16_t* y; float* hstate; float* saved; uint16_t* hprev_bf;
+    const float* dy; int64_t ld_dy; const uint16_t* mask;
+    uint16_t* dgi; uint16_t* dgh; float* dhstate;
+    int32_t B, T, H;
+} stes_gru_args;
+int stes_gru_forward(const stes_gru_args* a, void* stream);
+int stes_gru_backward(const stes_gru_args* a, void* stream);
+/* MinGRU recurrence, reference model/min_gru.py:76-92; pre = [gate pre-activation | candidate]. */
+int stes_mingru_scan_fwd(const uint16_t* pre, uint16_t* h, int B, int T, int H, void* stream);
+int stes_mingru_scan_bwd(const uint16_t* pre, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre, int B, int T,
+                         int H, void* stream);
+/* nn.Dropout of GRUPrediction (model/modules.py:32): out = x*mask, mask in {0, 1/(1-p)} from a counter hash. */
+int stes_dropout(const uint16_t* x, uint16_t* out, uint16_t* mask, int64_t n, float p, uint32_t seed, void* stream);
+/* Weighted-mean cross entropy + masked L1 on sigmoid(loc) (train_e2e_spatial.py:566-593) and their
+ * gradients (bf16, rows padded to 8 columns).  out_loss = {sum, cls, loc, sum of class weights,
+ * number of event frames}.  ext_denoms (optional) replaces the two denominators, e.g. by their
+ * sums over data-parallel ranks.                                                          */
+int stes_loss(const float* logits, int64_t ldl, const float* loc, int64_t ldloc, const int64_t* label, const float* xy,
+              int M, int C, float fg_weight, float grad_scale, const float* ext_denoms, float* out_loss,
+              uint16_t* dlogits, uint16_t* dloc, void* stream);
+/* torch.optim.AdamW update over a flat fp32 range (model/common.py:40, step() :61-75). */
+int stes_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, float grad_mul, void* stream);
+/* fp32 [rows][cols] -> bf16 [dst_rows][ld], optionally transposed, zero padded. */
+int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,537 @@
+// HBM-bound channel-vector kernels of the RegNet-Y bottleneck: BatchNorm finalisation,
+// BN-apply + residual + ReLU, squeeze-excite pooling / FC, BatchNorm backward reductions and
+// applications, the block-input gradient merge, global average pooling.
+//
+// Layout: NHWC bf16 viewed as [rows][C]; every thread owns one 8-channel (16-byte) chunk and walks
+// rows with a stride that keeps its chunk fixed, so per-channel reductions stay in registers until
+// one LDS + one global atomic per channel per workgroup.
+#include "stes_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__host__ int flat_grid(long rows, int ch, int max_blocks = 2048) {
+    // total threads must be a multiple of ch: grid a multiple of ch / gcd(ch, TPB)
+    int a = ch, b = TPB;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int unit = ch / a;
+    long want = (rows * ch + TPB - 1) / TPB;
+    if (want > max_blocks) want = max_blocks;
+    long g = (want + unit - 1) / unit * unit;
+    if (g < unit) g = unit;
+    return (int)g;
+}
+
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[i + 4] = b[i]; }
+}
+__device__ __forceinline__ void load8b(const bf16* p, float (&f)[8]) {
+    unpack8(*reinterpret_cast<const bf16x8*>(p), f);
+}
+__device__ __forceinline__ void store8b(bf16* p, const float (&f)[8]) {
+    *reinterpret_cast<bf16x8*>(p) = pack8(f);
+}
+
+// ---------------------------------------------------------------- BN finalize
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                   int training, float* scale, float* shift, float* smean, float* sinv, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        const double m = (double)sum[c] / count;
+        double v = (double)sumsq[c] / count - m * m;
+        if (v < 0) v = 0;
+        mean = (float)m; var = (float)v;
+        if (rmean) {
+            const double unb = count > 1 ? v * count / (count - 1) : v;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    } else {
+        mean = rmean[c]; var = rvar[c];
+    }
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * inv;
+    shift[c] = b - mean * g * inv;
+    if (smean) { smean[c] = mean; sinv[c] = inv; }
+}
+
+// ---------------------------------------------------------------- out = relu(bn(c) + residual)
+__global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
+    const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
+    bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, long M, int C) {
+    extern __shared__ float lds[];     // [2][stat_c]
+    const int CH = C / 8;
+    const long gt = (long)blockIdx.x * TPB + threadIdx.x;
+    const long TT = (long)gridDim.x * TPB;
+    const int chunk = (int)(gt % CH);
+    const long rstep = TT / CH;
+    const int c0 = chunk * 8;
+    float s[8], b[8], rs[8], rb[8];
+    load8f(scale + c0, s); load8f(shift + c0, b);
+    if (rscale) { load8f(rscale + c0, rs); load8f(rshift + c0, rb); }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+    for (int i = threadIdx.x; i < 2 * stat_c; i += TPB) lds[i] = 0.f;
+    for (long m = gt / CH; m < M; m += rstep) {
+        float v[8], r[8];
+        load8b(c + m * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * s[i] + b[i];
+        if (res) {
+            load8b(res + m * C + c0, r);
+            if (rscale) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += r[i] * rs[i] + rb[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += r[i];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o[i] = (bf16)fmaxf(v[i], 0.f); v[i] = (float)o[i]; }
+        *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+        if (c0 < stat_c) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
+        }
+    }
+    if (stat_c > 0) {
+        __syncthreads();
+        if (c0 < stat_c) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { atomicAdd(&lds[c0 + i], ssum[i]); atomicAdd(&lds[stat_c + c0 + i], ssq[i]); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < stat_c; i += TPB) {
+            atomicAdd(stat_sum + i, lds[i]);
+            atomicAdd(stat_sumsq + i, lds[stat_c + i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-image channel pooling
+// out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1);  act = relu(scale*c+shift) or identity
+__global__ void chan_pool_kernel(const bf16* __restrict__ c, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, const bf16* __restrict__ mul,
+                                 float* __restrict__ out, bf16* __restrict__ out_bf, int HW, int C, float norm, int R) {
+    extern __shared__ float lds[];     // [R][C]
+    const int CH = C / 8;
+    const int n = blockIdx.x;
+    const int chunk = threadIdx.x % CH, rg = threadIdx.x / CH;
+    const int c0 = chunk * 8;
+    float s[8], b[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (scale) { load8f(scale + c0, s); load8f(shift + c0, b); }
+    const bf16* base = c + (long)n * HW * C + c0;
+    const bf16* mbase = mul ? mul + (long)n * HW * C + c0 : nullptr;
+    for (int r = rg; r < HW; r += R) {
+        float v[8];
+        load8b(base + (long)r * C, v);
+        if (scale) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * s[i] + b[i], 0.f);
+        }
+        if (mbase) {
+            float w[8];
+            load8b(mbase + (long)r * C, w);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= w[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds[rg * C + c0 + i] = acc[i];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += lds[r * C + ch];
+        t *= norm;
+        if (out) out[(long)n * C + ch] = t;
+        if (out_bf) out_bf[(long)n * C + ch] = (bf16)t;
+    }
+}
+
+// ---------------------------------------------------------------- squeeze-excite FC (per image)
+__global__ __launch_bounds__(TPB) void se_fc_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ hidden,
+                                                    float* __restrict__ gate, int C, int R) {
+    extern __shared__ float lds[];     // pooled[C] + hidden[R]
+    float* sp = lds; float* sh = lds + C;
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < C; i += TPB) sp[i] = pooled[(long)n * C + i];
+    __syncthreads();
+    for (int r = wave; r < R; r += TPB / 64) {
+        float a = 0.f;
+        for (int k = lane; k < C; k += 64) a += w1[(long)r * C + k] * sp[k];
+        a = wave_sum(a);
+        if (lane == 0) { a = fmaxf(a + b1[r], 0.f); sh[r] = a; hidden[(long)n * R + r] = a; }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+        float a = b2[ch];
+        for (int r = 0; r < R; ++r) a += w2[(long)ch * R + r] * sh[r];
+        gate[(long)n * C + ch] = 1.f / (1.f + __expf(-a));
+    }
+}
+
+__global__ __launch_bounds__(TPB) void se_fc_bwd_kernel(const float* __restrict__ dgate_raw, const float* __restrict__ gate,
+                                                        const float* __restrict__ hidden, const float* __restrict__ w1,
+                                                        const float* __restrict__ w2, float* __restrict__ dpre2,
+                                                        float* __restrict__ dpre1, float* __restrict__ dpool,
+                                                        float inv_hw, int C, int R) {
+    extern __shared__ float lds[];     // d2[C] + d1[R]
+    float* s2 = lds; float* s1 = lds + C;
+    const int n = blockIdx.x;
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+        const float g = gate[(long)n * C + ch];
+        const float d = dgate_raw[(long)n * C + ch] * g * (1.f - g);
+        s2[ch] = d; dpre2[(long)n * C + ch] = d;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += TPB) {
+        float a = 0.f;
+        for (int ch = 0; ch < C; ++ch) a += w2[(long)ch * R + r] * s2[ch];
+        a = hidden[(long)n * R + r] > 0.f ? a : 0.f;
+        s1[r] = a; dpre1[(long)n * R + r] = a;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a += w1[(long)r * C + ch] * s1[r];
+        dpool[(long)n * C + ch] = a * inv_hw;
+    }
+}
+
+// dW[n1,n2] += sum_n P[n,n1] Q[n,n2];  db[n1] += sum_n P[n,n1]   (fp32, small)
+__global__ __launch_bounds__(TPB) void f32_outer_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                        float* __restrict__ dW, float* __restrict__ db, int N, int n1, int n2) {
+    __shared__ float sp[32][17], sq[32][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    float acc = 0.f, bacc = 0.f;
+    for (int nb = 0; nb < N; nb += 32) {
+        for (int e = threadIdx.x; e < 512; e += TPB) {
+            const int r = e >> 4, cc = e & 15, n = nb + r;
+            sp[r][cc] = (n < N && i0 + cc < n1) ? P[(long)n * n1 + i0 + cc] : 0.f;
+            sq[r][cc] = (n < N && j0 + cc < n2) ? Q[(long)n * n2 + j0 + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) { acc += sp[r][ty] * sq[r][tx]; bacc += sp[r][ty]; }
+        __syncthreads();
+    }
+    if (i0 + ty < n1 && j0 + tx < n2) dW[(long)(i0 + ty) * n2 + j0 + tx] += acc;
+    if (db && blockIdx.y == 0 && tx == 0 && i0 + ty < n1) db[i0 + ty] += bacc;
+}
+
+// ---------------------------------------------------------------- BN backward
+struct DySrc {
+    const bf16* D; const float* mul; const float* add; int group;
+    const bf16* act_raw; const float* act_scale; const float* act_shift;
+};
+
+// dY for 8 channels of row m
+__device__ __forceinline__ void compute_dy(const DySrc& d, long m, int C, int c0, const float (&as)[8], const float (&ab)[8],
+                                           float (&dy)[8]) {
+    load8b(d.D + m * C + c0, dy);
+    if (d.mul) {
+        float mu[8];
+        load8f(d.mul + (m / d.group) * C + c0, mu);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dy[i] *= mu[i];
+    }
+    if (d.add) {
+        float ad[8];
+        load8f(d.add + (m / d.group) * C + c0, ad);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dy[i] += ad[i];
+    }
+    if (d.act_raw) {
+        float a[8];
+        load8b(d.act_raw + m * C + c0, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dy[i] = (a[i] * as[i] + ab[i] > 0.f) ? dy[i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_args p) {
+    extern __shared__ float lds[];     // [3][C]
+    const int C = p.C, CH = C / 8;
+    const long gt = (long)blockIdx.x * TPB + threadIdx.x;
+    const long TT = (long)gridDim.x * TPB;
+    const int c0 = (int)(gt % CH) * 8;
+    const long rstep = TT / CH;
+    DySrc d{(const bf16*)p.D, p.mul, p.add, p.group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
+    float as[8], ab[8];
+    if (d.act_raw) { load8f(p.act_scale + c0, as); load8f(p.act_shift + c0, ab); }
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = threadIdx.x; i < 3 * C; i += TPB) lds[i] = 0.f;
+    const bf16* r1 = (const bf16*)p.raw1; const bf16* r2 = (const bf16*)p.raw2;
+    for (long m = gt / CH; m < p.M; m += rstep) {
+        float dy[8], a[8];
+        compute_dy(d, m, C, c0, as, ab, dy);
+        load8b(r1 + m * C + c0, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0[i] += dy[i]; s1[i] += dy[i] * a[i]; }
+        if (r2) {
+            load8b(r2 + m * C + c0, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s2[i] += dy[i] * a[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&lds[c0 + i], s0[i]); atomicAdd(&lds[C + c0 + i], s1[i]);
+        if (r2) atomicAdd(&lds[2 * C + c0 + i], s2[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += TPB) {
+        atomicAdd(p.s_dy + i, lds[i]);
+        atomicAdd(p.s_dyr1 + i, lds[C + i]);
+        if (r2) atomicAdd(p.s_dyr2 + i, lds[2 * C + i]);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* s_dy, const float* s_dyr, const float* mean, const float* invstd,
+                                       const float* gamma, double count, float* alpha, float* beta, float* delta,
+                                       float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float inv = invstd[c], mu = mean[c];
+    const float db = s_dy[c];
+    const float dg = inv * (s_dyr[c] - mu * db);                // sum dY * xhat
+    const float k = g * inv;
+    const float inv_n = (float)(1.0 / count);
+    alpha[c] = k;
+    beta[c] = -k * inv * dg * inv_n;
+    delta[c] = -k * db * inv_n + k * inv * mu * dg * inv_n;
+    if (dgamma) dgamma[c] += dg;
+    if (dbeta) dbeta[c] += db;
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const stes_bn_bwd_args p) {
+    const int C = p.C, CH = C / 8;
+    const long gt = (long)blockIdx.x * TPB + threadIdx.x;
+    const long TT = (long)gridDim.x * TPB;
+    const int c0 = (int)(gt % CH) * 8;
+    const long rstep = TT / CH;
+    DySrc d{(const bf16*)p.D, p.mul, p.add, p.group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
+    float as[8], ab[8], al[8], be[8], de[8];
+    if (d.act_raw) { load8f(p.act_scale + c0, as); load8f(p.act_shift + c0, ab); }
+    load8f(p.alpha + c0, al); load8f(p.beta + c0, be); load8f(p.delta + c0, de);
+    const bf16* r1 = (const bf16*)p.raw1;
+    bf16* out = (bf16*)p.out;
+    for (long m = gt / CH; m < p.M; m += rstep) {
+        float dy[8], a[8];
+        compute_dy(d, m, C, c0, as, ab, dy);
+        load8b(r1 + m * C + c0, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dy[i] = al[i] * dy[i] + be[i] * a[i] + de[i];
+        store8b(out + m * C + c0, dy);
+    }
+}
+
+// ---------------------------------------------------------------- block input gradient
+// out[m,c] = ((c < fold ? dXf[m,c] : dY[m,c]) + residual) * (X[m,c] > 0)
+__global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restrict__ dY, long ldy, const bf16* __restrict__ dXf,
+                                                            int fold, const bf16* __restrict__ resid, int ms, int Ho, int Wo,
+                                                            int Hi, int Wi, const bf16* __restrict__ X, bf16* __restrict__ out,
+                                                            long M, int C) {
+    const int CH = C / 8;
+    const long total = M * CH;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long m = i / CH; const int c0 = (int)(i - m * CH) * 8;
+        float v[8], x[8];
+        if (c0 < fold) load8b(dXf + m * fold + c0, v); else load8b(dY + m * ldy + c0, v);
+        if (resid) {
+            long rm = m; bool ok = true;
+            if (ms > 1) {
+                const long hw = (long)Hi * Wi;
+                const long n = m / hw; const int rem = (int)(m - n * hw);
+                const int hi = rem / Wi, wi = rem - hi * Wi;
+                ok = (hi % ms == 0) && (wi % ms == 0) && (hi / ms < Ho) && (wi / ms < Wo);
+                rm = (n * Ho + hi / ms) * Wo + wi / ms;
+            }
+            if (ok) {
+                float r[8];
+                load8b(resid + rm * C + c0, r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += r[k];
+            }
+        }
+        load8b(X + m * C + c0, x);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = x[k] > 0.f ? v[k] : 0.f;
+        store8b(out + m * C + c0, v);
+    }
+}
+
+// dZ[m,c] = (da[n,c] + db[n,c]) * inv_hw * (out[m,c] > 0)
+__global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__ da, const float* __restrict__ db,
+                                                       const bf16* __restrict__ outp, bf16* __restrict__ dZ, int HW, int C,
+                                                       float inv_hw, long M) {
+    const int CH = C / 8;
+    const long total = M * CH;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long m = i / CH; const int c0 = (int)(i - m * CH) * 8;
+        const long n = m / HW;
+        float g[8], o[8];
+        load8f(da + n * C + c0, g);
+        if (db) {
+            float h[8];
+            load8f(db + n * C + c0, h);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] += h[k];
+        }
+        load8b(outp + m * C + c0, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] * inv_hw : 0.f;
+        store8b(dZ + m * C + c0, g);
+    }
+}
+
+}  // namespace
+
+#define S(s) ((hipStream_t)(s))
+
+extern "C" int stes_bn_finalize(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int training,
+                                float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
+    STES_CHECK(scale && shift && C > 0, STES_ERR_ARG, "stes_bn_finalize: null output");
+    STES_CHECK(training ? (sum && sumsq && count > 0) : (running_mean && running_var), STES_ERR_ARG, "stes_bn_finalize: missing statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(stes_div_up(C, 128)), dim3(128), 0, S(stream), sum, sumsq, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_invstd, C);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
+                                    const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
+                                    float* stat_sumsq, int stat_c, int64_t M, int C, void* stream) {
+    STES_CHECK(c && scale && shift && out && M > 0, STES_ERR_ARG, "stes_bn_act_residual: null pointer");
+    STES_CHECK(C % 8 == 0 && stat_c % 8 == 0 && stat_c <= C, STES_ERR_ARG, "stes_bn_act_residual: C and stat_c must be multiples of 8");
+    STES_CHECK(stat_c == 0 || (stat_sum && stat_sumsq), STES_ERR_ARG, "stes_bn_act_residual: stats pointers");
+    const int grid = flat_grid(M, C / 8);
+    hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
+                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (long)M, C);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, const uint16_t* mul, float* out,
+                              uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream) {
+    STES_CHECK(c && (out || out_bf16) && N > 0 && HW > 0, STES_ERR_ARG, "stes_chan_pool: null pointer");
+    STES_CHECK(C % 8 == 0 && C / 8 <= TPB, STES_ERR_ARG, "stes_chan_pool: C must be a multiple of 8, at most 2048");
+    const int CH = C / 8;
+    int R = TPB / CH;
+    if (R > HW) R = HW;
+    if (R < 1) R = 1;
+    hipLaunchKernelGGL(chan_pool_kernel, dim3(N), dim3(CH * R), (size_t)R * C * sizeof(float), S(stream), (const bf16*)c, scale, shift,
+                       (const bf16*)mul, out, (bf16*)out_bf16, HW, C, norm, R);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_se_fc(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                          float* hidden, float* gate, int N, int C, int R, void* stream) {
+    STES_CHECK(pooled && w1 && b1 && w2 && b2 && hidden && gate, STES_ERR_ARG, "stes_se_fc: null pointer");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(TPB), (size_t)(C + R) * sizeof(float), S(stream), pooled, w1, b1, w2, b2, hidden, gate, C, R);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_se_fc_bwd(const float* dgate_raw, const float* gate, const float* hidden, const float* w1, const float* w2,
+                              float* dpre2, float* dpre1, float* dpool, float inv_hw, int N, int C, int R, void* stream) {
+    STES_CHECK(dgate_raw && gate && hidden && w1 && w2 && dpre2 && dpre1 && dpool, STES_ERR_ARG, "stes_se_fc_bwd: null pointer");
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(TPB), (size_t)(C + R) * sizeof(float), S(stream), dgate_raw, gate, hidden, w1, w2,
+                       dpre2, dpre1, dpool, inv_hw, C, R);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_f32_outer(const float* P, const float* Q, float* dW, float* db, int N, int n1, int n2, void* stream) {
+    STES_CHECK(P && Q && dW && N > 0, STES_ERR_ARG, "stes_f32_outer: null pointer");
+    hipLaunchKernelGGL(f32_outer_kernel, dim3(stes_div_up(n1, 16), stes_div_up(n2, 16)), dim3(TPB), 0, S(stream), P, Q, dW, db, N, n1, n2);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+static int check_bwd(const stes_bn_bwd_args* a, const char* who) {
+    STES_CHECK(a && a->D && a->raw1 && a->M > 0, STES_ERR_ARG, who);
+    STES_CHECK(a->C % 8 == 0, STES_ERR_ARG, "bn_bwd: C must be a multiple of 8");
+    STES_CHECK((!a->mul && !a->add) || a->group > 0, STES_ERR_ARG, "bn_bwd: group");
+    STES_CHECK(!a->act_raw || (a->act_scale && a->act_shift), STES_ERR_ARG, "bn_bwd: mask affine");
+    return STES_OK;
+}
+
+extern "C" int stes_bn_bwd_reduce(const stes_bn_bwd_args* a, void* stream) {
+    int rc = check_bwd(a, "stes_bn_bwd_reduce: null pointer");
+    if (rc) return rc;
+    STES_CHECK(a->s_dy && a->s_dyr1 && (!a->raw2 || a->s_dyr2), STES_ERR_ARG, "stes_bn_bwd_reduce: outputs");
+    const int grid = flat_grid(a->M, a->C / 8, 1024);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(TPB), 3 * a->C * sizeof(float), S(stream), *a);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_bn_bwd_finalize(const float* s_dy, const float* s_dyr, const float* mean, const float* invstd,
+                                    const float* gamma, double count, float* alpha, float* beta, float* delta,
+                                    float* dgamma, float* dbeta, int C, void* stream) {
+    STES_CHECK(s_dy && s_dyr && mean && invstd && alpha && beta && delta && count > 0, STES_ERR_ARG, "stes_bn_bwd_finalize: null pointer");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(stes_div_up(C, 128)), dim3(128), 0, S(stream), s_dy, s_dyr, mean, invstd, gamma,
+                       count, alpha, beta, delta, dgamma, dbeta, C);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream) {
+    int rc = check_bwd(a, "stes_bn_bwd_apply: null pointer");
+    if (rc) return rc;
+    STES_CHECK(a->alpha && a->beta && a->delta && a->out, STES_ERR_ARG, "stes_bn_bwd_apply: coefficients/output");
+    const int grid = flat_grid(a->M, a->C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(TPB), 0, S(stream), *a);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
+                                  int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
+                                  int64_t M, int C, void* stream) {
+    STES_CHECK(dY && X && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
+    STES_CHECK(C % 8 == 0 && fold % 8 == 0 && ldy % 8 == 0 && (fold == 0 || dXf), STES_ERR_ARG, "stes_block_in_grad: alignment");
+    long blocks = (M * (C / 8) + TPB - 1) / TPB;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(block_in_grad_kernel, dim3((int)blocks), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf, fold,
+                       (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_t* dZ, int N, int HW, int C,
+                             void* stream) {
+    STES_CHECK(da && out && dZ && N > 0 && HW > 0 && C % 8 == 0, STES_ERR_ARG, "stes_pool_bwd: bad argument");
+    const long M = (long)N * HW;
+    long blocks = (M * (C / 8) + TPB - 1) / TPB;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, S(stream), da, db, (const bf16*)out, (bf16*)dZ, HW, C,
+                       1.0f / HW, M);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}

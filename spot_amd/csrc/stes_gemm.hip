@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
                     v[r] = acc[i][j][r] + bias[r];
                     if (p.act == 1) v[r] = fmaxf(v[r], 0.f);
                 }
+                if (p.relu_mask) {
+                    const bf16* mk = (const bf16*)p.relu_mask + m * p.ldmask + nb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (nb + r < N && !((float)mk[r] > 0.f)) v[r] = 0.f;
+                }
                 if (p.c_f32) {
                     float* c = (float*)p.C + m * p.ldc + nb;
                     if (nb + 3 < N && (p.ldc & 3) == 0) {

@@ -1,0 +1,364 @@
+// Temporal head and training-step kernels: GRU recurrence (forward / BPTT step), minGRU scan,
+// dropout mask, weighted-CE + masked-L1 loss with its gradient, AdamW, fp32 -> bf16 weight casts.
+//
+// GRU (torch.nn.GRU semantics, gate order r,z,n; reference model/modules.py:24-30): the input
+// projection of every time step is one big MFMA GEMM done beforehand (stes_gemm).  The recurrence
+// is one launch per time step; a workgroup owns 16 hidden units of one direction for all (<=16)
+// batch rows, its 4 waves split K = H for the [B,H] x [H,3*16] product on
+// v_mfma_f32_16x16x32_bf16 with the hidden state as the A operand (read straight from the output
+// sequence) and the W_hh rows as B, then the gate math runs on the accumulator layout.
+#include "stes_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------ GRU forward step
+// grid (H/16, 2 dirs, batch tiles of 16); block 256
+__global__ __launch_bounds__(256) void gru_fwd_step_kernel(const stes_gru_args p, int step) {
+    __shared__ float red[4][64][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int dir = blockIdx.y, j0 = blockIdx.x * 16, b0 = blockIdx.z * 16;
+    const int H = p.H, T = p.T, B = p.B;
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tprev = dir == 0 ? t - 1 : t + 1;
+    const bf16* y = (const bf16*)p.y;
+    const bf16* __restrict__ whh = (const bf16*)p.whh + (long)dir * 3 * H * H;
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+        const int nk = H / 32;
+        const int brow = b0 + fr;
+        const bf16* arow = (brow < B) ? y + ((long)brow * T + tprev) * 2 * H + dir * H : nullptr;
+        for (int ks = wave; ks < nk; ks += 4) {
+            const int k = ks * 32 + fq * 8;
+            const bf16x8 fa = arow ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(whh + ((long)g * H + j0 + fr) * H + k);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[g], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][lane][g * 4 + r] = acc[g][r];
+    __syncthreads();
+    if (wave != 0) return;
+    const int j = j0 + fr;
+    const float* bhh = p.bhh + (long)dir * 3 * H;
+    const float bh_r = bhh[j], bh_z = bhh[H + j], bh_n = bhh[2 * H + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + fq * 4 + r;
+        if (b >= B) continue;
+        float gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gh[g] = red[0][lane][g * 4 + r] + red[1][lane][g * 4 + r] + red[2][lane][g * 4 + r] + red[3][lane][g * 4 + r];
+        const bf16* gi = (const bf16*)p.gi + (((long)b * T + t) * 2 + dir) * 3 * H;
+        const float ir = (float)gi[j], iz = (float)gi[H + j], in = (float)gi[2 * H + j];
+        const float hp = step > 0 ? p.hstate[(((long)dir * 2 + ((step - 1) & 1)) * B + b) * H + j] : 0.f;
+        const float hn = gh[2] + bh_n;
+        const float rg = sigmoidf_(ir + gh[0] + bh_r);
+        const float zg = sigmoidf_(iz + gh[1] + bh_z);
+        const float ng = tanhf(in + rg * hn);
+        const float h = (1.f - zg) * ng + zg * hp;
+        p.hstate[(((long)dir * 2 + (step & 1)) * B + b) * H + j] = h;
+        ((bf16*)p.y)[((long)b * T + t) * 2 * H + dir * H + j] = (bf16)h;
+        if (p.saved) {
+            float* sv = p.saved + ((((long)dir * T + t) * B + b) * 5) * H;      // r, z, n, hn, hprev
+            sv[j] = rg; sv[H + j] = zg; sv[2 * H + j] = ng; sv[3 * H + j] = hn; sv[4 * H + j] = hp;
+            ((bf16*)p.hprev_bf)[(((long)dir * T + t) * B + b) * H + j] = (bf16)hp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GRU backward step
+__global__ __launch_bounds__(256) void gru_bwd_step_kernel(const stes_gru_args p, int step) {
+    __shared__ float red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int dir = blockIdx.y, j0 = blockIdx.x * 16, b0 = blockIdx.z * 16;
+    const int H = p.H, T = p.T, B = p.B;
+    // backward walks the forward order in reverse: forward step index s = T-1-step
+    const int s = T - 1 - step;
+    const int t = dir == 0 ? s : T - 1 - s;
+    const int tnext = dir == 0 ? t + 1 : t - 1;          // time whose gate gradients were produced by the previous bwd step
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bf16* dgh_all = (bf16*)p.dgh;                         // [2][T][B][3H]
+    if (step > 0) {
+        const bf16* __restrict__ whhT = (const bf16*)p.whhT + (long)dir * 3 * H * H;   // [H][3H]
+        const int K = 3 * H, nk = K / 32;
+        const int brow = b0 + fr;
+        const bf16* arow = (brow < B) ? dgh_all + (((long)dir * T + tnext) * B + brow) * K : nullptr;
+        for (int ks = wave; ks < nk; ks += 4) {
+            const int k = ks * 32 + fq * 8;
+            const bf16x8 fa = arow ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(whhT + (long)(j0 + fr) * K + k);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+    const int j = j0 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + fq * 4 + r;
+        if (b >= B) continue;
+        float dh = red[0][lane][r] + red[1][lane][r] + red[2][lane][r] + red[3][lane][r];
+        if (step > 0) dh += p.dhstate[(((long)dir * 2 + ((step - 1) & 1)) * B + b) * H + j];
+        float dy = p.dy[((long)b * T + t) * p.ld_dy + dir * H + j];
+        if (p.mask) dy *= (float)((const bf16*)p.mask)[((long)b * T + t) * 2 * H + dir * H + j];
+        dh += dy;
+        const float* sv = p.saved + ((((long)dir * T + t) * B + b) * 5) * H;
+        const float rg = sv[j], zg = sv[H + j], ng = sv[2 * H + j], hn = sv[3 * H + j], hp = sv[4 * H + j];
+        const float dn = dh * (1.f - zg);
+        const float dz = dh * (hp - ng);
+        const float dnp = dn * (1.f - ng * ng);
+        const float drp = dnp * hn * rg * (1.f - rg);
+        const float dzp = dz * zg * (1.f - zg);
+        p.dhstate[(((long)dir * 2 + (step & 1)) * B + b) * H + j] = dh * zg;
+        bf16* dgi = (bf16*)p.dgi + (((long)b * T + t) * 2 + dir) * 3 * H;
+        dgi[j] = (bf16)drp; dgi[H + j] = (bf16)dzp; dgi[2 * H + j] = (bf16)dnp;
+        bf16* dg = dgh_all + (((long)dir * T + t) * B + b) * 3 * H;
+        dg[j] = (bf16)drp; dg[H + j] = (bf16)dzp; dg[2 * H + j] = (bf16)(dnp * rg);
+    }
+}
+
+// ------------------------------------------------------------------ minGRU scan (reference model/min_gru.py:76-92)
+// pre [B,T,2H] bf16: columns [0,H) gate pre-activation, [H,2H) candidate; h_t = (1-z) h_{t-1} + z * cand, h_0 = 0
+__global__ void mingru_scan_fwd_kernel(const bf16* __restrict__ pre, bf16* __restrict__ h, int B, int T, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    float hp = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const bf16* r = pre + ((long)b * T + t) * 2 * H;
+        const float z = sigmoidf_((float)r[j]);
+        hp = (1.f - z) * hp + z * (float)r[H + j];
+        h[((long)b * T + t) * H + j] = (bf16)hp;
+    }
+}
+// dpre [B,T,2H] bf16 from dh [B,T,ld] f32; hidden states re-read from h (bf16)
+__global__ void mingru_scan_bwd_kernel(const bf16* __restrict__ pre, const bf16* __restrict__ h, const float* __restrict__ dh, long ld_dh,
+                                       bf16* __restrict__ dpre, int B, int T, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    float carry = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const bf16* r = pre + ((long)b * T + t) * 2 * H;
+        const float z = sigmoidf_((float)r[j]), cand = (float)r[H + j];
+        const float hp = t > 0 ? (float)h[((long)b * T + t - 1) * H + j] : 0.f;
+        const float g = dh[((long)b * T + t) * ld_dh + j] + carry;
+        bf16* o = dpre + ((long)b * T + t) * 2 * H;
+        o[j] = (bf16)(g * (cand - hp) * z * (1.f - z));
+        o[H + j] = (bf16)(g * z);
+        carry = g * (1.f - z);
+    }
+}
+
+// ------------------------------------------------------------------ dropout
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// out = x * mask, mask = keep ? 1/(1-p) : 0 (mask stored as bf16 for the backward)
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, bf16* __restrict__ mask, long n, float p,
+                               uint32_t seed) {
+    const float inv = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t r = mix32((uint32_t)i * 0x9E3779B9U + seed) ^ mix32((uint32_t)(i >> 32) + seed * 0x85ebca6bU);
+        const float u = (r >> 8) * (1.0f / 16777216.0f);
+        const float m = u >= p ? inv : 0.f;
+        mask[i] = (bf16)m;
+        out[i] = (bf16)((float)x[i] * m);
+    }
+}
+
+// ------------------------------------------------------------------ loss (reference train_e2e_spatial.py:566-593)
+// single workgroup; rows = B*T frames
+__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ loc, long ldloc,
+                                                    const int64_t* __restrict__ label, const float* __restrict__ xy, int M, int C,
+                                                    float fg_weight, float grad_scale, const float* ext_denoms, float* out_loss,
+                                                    bf16* __restrict__ dlogits, bf16* __restrict__ dloc) {
+    __shared__ float red[4][32];
+    __shared__ float tot[4];
+    float wsum = 0.f, msum = 0.f, ce = 0.f, l1 = 0.f;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const int yv = (int)label[m];
+        const float w = yv == 0 ? 1.f : fg_weight;
+        const float* lg = logits + (long)m * ldl;
+        float mx = lg[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(lg[c] - mx);
+        ce += w * (logf(se) + mx - lg[yv]);
+        wsum += w;
+        if (loc && yv != 0) {
+            msum += 1.f;
+            for (int d = 0; d < 2; ++d) l1 += fabsf(sigmoidf_(loc[(long)m * ldloc + d]) - xy[(long)m * 2 + d]);
+        }
+    }
+    float v[4] = {wsum, msum, ce, l1};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = wave_sum(v[k]); if (lane == 0) red[k][wave] = v[k]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[threadIdx.x][w];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    // denominators: local, or supplied (sum over all data-parallel ranks)
+    const float wden = ext_denoms ? ext_denoms[0] : tot[0];
+    const float mden = (ext_denoms ? ext_denoms[1] : tot[1]) + 1e-6f;
+    if (threadIdx.x == 0) {
+        const float lc = tot[2] / wden, ll = loc ? tot[3] / mden : 0.f;
+        out_loss[0] = lc + ll; out_loss[1] = lc; out_loss[2] = ll; out_loss[3] = tot[0]; out_loss[4] = tot[1];
+    }
+    if (!dlogits) return;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const int yv = (int)label[m];
+        const float w = (yv == 0 ? 1.f : fg_weight) / wden * grad_scale;
+        const float* lg = logits + (long)m * ldl;
+        float mx = lg[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(lg[c] - mx);
+        const float inv = 1.f / se;
+        const int ldd = (C + 7) / 8 * 8;
+        for (int c = 0; c < ldd; ++c) {
+            float g = 0.f;
+            if (c < C) g = w * (__expf(lg[c] - mx) * inv - (c == yv ? 1.f : 0.f));
+            dlogits[(long)m * ldd + c] = (bf16)g;
+        }
+        if (dloc) {
+            for (int d = 0; d < 8; ++d) {
+                float g = 0.f;
+                if (d < 2 && yv != 0) {
+                    const float sg = sigmoidf_(loc[(long)m * ldloc + d]);
+                    const float df = sg - xy[(long)m * 2 + d];
+                    g = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * sg * (1.f - sg) / mden * grad_scale;
+                }
+                dloc[(long)m * 8 + d] = (bf16)g;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW, used at model/common.py:40)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float grad_mul) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * grad_mul;
+        float pv = p[i] * (1.f - lr * wd);
+        const float mv = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pv -= (lr / bc1) * mv / denom;
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+
+// ------------------------------------------------------------------ fp32 -> bf16 weight copies
+// dst[r][c] = src[r][c] (transpose = 0) or dst[c][r] = src[r][c] (transpose = 1); dst rows padded with zeros to ld
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ld, int dst_rows, int transpose) {
+    const long total = (long)dst_rows * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dr = (int)(i / ld), dc = (int)(i - (long)dr * ld);
+        float v = 0.f;
+        if (!transpose) { if (dr < rows && dc < cols) v = src[(long)dr * cols + dc]; }
+        else { if (dc < rows && dr < cols) v = src[(long)dc * cols + dr]; }
+        dst[i] = (bf16)v;
+    }
+}
+
+}  // namespace
+
+#define S(s) ((hipStream_t)(s))
+
+static int gru_check(const stes_gru_args* a) {
+    STES_CHECK(a && a->gi && a->whh && a->bhh && a->y && a->hstate, STES_ERR_ARG, "stes_gru: null pointer");
+    STES_CHECK(a->H % 32 == 0 && a->B > 0 && a->T > 0, STES_ERR_ARG, "stes_gru: H must be a multiple of 32");
+    return STES_OK;
+}
+
+extern "C" int stes_gru_forward(const stes_gru_args* a, void* stream) {
+    int rc = gru_check(a); if (rc) return rc;
+    STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward: saved needs hprev_bf");
+    const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
+    for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_gru_backward(const stes_gru_args* a, void* stream) {
+    int rc = gru_check(a); if (rc) return rc;
+    STES_CHECK(a->saved && a->whhT && a->dy && a->dgi && a->dgh && a->dhstate && a->ld_dy >= 2 * a->H, STES_ERR_ARG, "stes_gru_backward: null pointer");
+    const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
+    for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_mingru_scan_fwd(const uint16_t* pre, uint16_t* h, int B, int T, int H, void* stream) {
+    STES_CHECK(pre && h && B > 0 && T > 0 && H > 0, STES_ERR_ARG, "stes_mingru_scan_fwd: bad argument");
+    hipLaunchKernelGGL(mingru_scan_fwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, (bf16*)h, B, T, H);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_mingru_scan_bwd(const uint16_t* pre, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre, int B, int T,
+                                    int H, void* stream) {
+    STES_CHECK(pre && h && dh && dpre && ld_dh >= H, STES_ERR_ARG, "stes_mingru_scan_bwd: bad argument");
+    hipLaunchKernelGGL(mingru_scan_bwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, (const bf16*)h,
+                       dh, (long)ld_dh, (bf16*)dpre, B, T, H);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_dropout(const uint16_t* x, uint16_t* out, uint16_t* mask, int64_t n, float p, uint32_t seed, void* stream) {
+    STES_CHECK(x && out && mask && n > 0 && p >= 0.f && p < 1.f, STES_ERR_ARG, "stes_dropout: bad argument");
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)x, (bf16*)out, (bf16*)mask, (long)n, p, seed);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_loss(const float* logits, int64_t ldl, const float* loc, int64_t ldloc, const int64_t* label, const float* xy,
+                         int M, int C, float fg_weight, float grad_scale, const float* ext_denoms, float* out_loss,
+                         uint16_t* dlogits, uint16_t* dloc, void* stream) {
+    STES_CHECK(logits && label && out_loss && M > 0 && C > 0 && ldl >= C, STES_ERR_ARG, "stes_loss: bad argument");
+    STES_CHECK(!loc || (xy && ldloc >= 2), STES_ERR_ARG, "stes_loss: location targets");
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, S(stream), logits, (long)ldl, loc, (long)ldloc, label, xy, M, C, fg_weight,
+                       grad_scale, ext_denoms, out_loss, (bf16*)dlogits, (bf16*)dloc);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float grad_mul, void* stream) {
+    STES_CHECK(p && g && m && v && n > 0 && step >= 1, STES_ERR_ARG, "stes_adamw: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, S(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), grad_mul);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, void* stream) {
+    STES_CHECK(src && dst && rows > 0 && cols > 0, STES_ERR_ARG, "stes_cast_bf16: bad argument");
+    STES_CHECK(transpose ? (ld >= rows && dst_rows >= cols) : (ld >= cols && dst_rows >= rows), STES_ERR_ARG, "stes_cast_bf16: destination too small");
+    long blocks = ((long)dst_rows * ld + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, S(stream), src, (bf16*)dst, rows, cols, ld, dst_rows, transpose);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}

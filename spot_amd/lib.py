@@ -20,38 +20,7 @@ class StesError(RuntimeError):
     pass
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise StesError(f"{LIB_PATH} not found: build it with `python -m spot_amd.build` "
-                            "(hipcc --offload-arch=gfx950); there is no fallback path")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.stes_last_error.restype = C.c_char_p
-        _lib.stes_version.restype = C.c_int
-    return _lib
-
-
-def check(rc: int, what: str):
-    if rc != 0:
-        raise StesError(f"{what} failed ({rc}): {lib().stes_last_error().decode()}")
-
-
-def stream_ptr() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def ptr(t):
-    """Device pointer of a tensor (or None)."""
-    if t is None:
-        return None
-    return t.data_ptr()
-
-
-_P = C.c_void_p
-_I32 = C.c_int32
-_I64 = C.c_int64
-_F32 = C.c_float
+_P, _I32, _I64, _F32, _F64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
 
 
 def _struct(name, fields):
@@ -66,6 +35,7 @@ GemmArgs = _struct("GemmArgs", [
     ("W", _P), ("ldw", _I64), ("bias", _P), ("act", _I32),
     ("C", _P), ("ldc", _I64), ("c_f32", _I32),
     ("col_sum", _P), ("col_sumsq", _P),
+    ("relu_mask", _P), ("ldmask", _I64),
     ("M", _I64), ("N", _I32), ("K", _I32)])
 
 WgradArgs = _struct("WgradArgs", [
@@ -75,10 +45,101 @@ WgradArgs = _struct("WgradArgs", [
     ("dW", _P), ("lddw", _I64), ("dbias", _P),
     ("M", _I64), ("N1", _I32), ("N2", _I32)])
 
+BnBwdArgs = _struct("BnBwdArgs", [
+    ("D", _P), ("mul", _P), ("add", _P), ("group", _I32),
+    ("act_raw", _P), ("act_scale", _P), ("act_shift", _P),
+    ("raw1", _P), ("raw2", _P),
+    ("s_dy", _P), ("s_dyr1", _P), ("s_dyr2", _P),
+    ("alpha", _P), ("beta", _P), ("delta", _P), ("out", _P),
+    ("M", _I64), ("C", _I32)])
 
+GsmGeom = _struct("GsmGeom", [("B", _I32), ("T", _I32), ("H", _I32), ("W", _I32), ("ldx", _I32), ("fold", _I32)])
+
+GruArgs = _struct("GruArgs", [
+    ("gi", _P), ("whh", _P), ("whhT", _P), ("bhh", _P),
+    ("y", _P), ("hstate", _P), ("saved", _P), ("hprev_bf", _P),
+    ("dy", _P), ("ld_dy", _I64), ("mask", _P),
+    ("dgi", _P), ("dgh", _P), ("dhstate", _P),
+    ("B", _I32), ("T", _I32), ("H", _I32)])
+
+_SIGS = {
+    "stes_gemm": [_P, _P],
+    "stes_wgrad": [_P, _P],
+    "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
+    "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _P],
+    "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
+    "stes_se_fc": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_se_fc_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "stes_f32_outer": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_bn_bwd_reduce": [_P, _P],
+    "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
+    "stes_bn_bwd_apply": [_P, _P],
+    "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P],
+    "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_pack_conv3x3g": [_P, _P, _P, _I32, _P],
+    "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_conv3x3g_dgrad": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "stes_gsm_gate": [_P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_shift": [_P, _P, _P, _P, _P],
+    "stes_gsm_bwd_gate": [_P, _I64, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_bnreduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_dx": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_col_stats": [_P, _I64, _I32, _I64, _P, _P, _P],
+    "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_gru_forward": [_P, _P],
+    "stes_gru_backward": [_P, _P],
+    "stes_mingru_scan_fwd": [_P, _P, _I32, _I32, _I32, _P],
+    "stes_mingru_scan_bwd": [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
+    "stes_dropout": [_P, _P, _P, _I64, _F32, _U32, _P],
+    "stes_loss": [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _F32, _F32, _P, _P, _P, _P, _P],
+    "stes_adamw": [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _F32, _P],
+    "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+}
+EXPORTS = ["stes_version", "stes_last_error"] + list(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StesError(f"{LIB_PATH} not found: build it with `python -m spot_amd.build` "
+                            "(hipcc --offload-arch=gfx950); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.stes_last_error.restype = C.c_char_p
+        L.stes_version.restype = C.c_int
+        for name, sig in _SIGS.items():
+            f = getattr(L, name)
+            f.argtypes = sig
+            f.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise StesError(f"{what} failed ({rc}): {lib().stes_last_error().decode()}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args, stream()), name)
+
+
+# ---------------------------------------------------------------- struct-argument entry points
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
-         bias=None, act=0, stats=None):
+         bias=None, act=0, stats=None, relu_mask=None, ldmask=0):
     """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
@@ -92,8 +153,9 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     a.C, a.ldc, a.c_f32 = ptr(Cout), ldc if ldc is not None else N, int(Cout.dtype == torch.float32)
     if stats is not None:
         a.col_sum, a.col_sumsq = ptr(stats[0]), ptr(stats[1])
+    a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
     a.M, a.N, a.K = M, N, K
-    check(lib().stes_gemm(C.byref(a), stream_ptr()), "stes_gemm")
+    check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
 
 
 def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0, k0=0,
@@ -109,4 +171,44 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
         a.map_stride, a.Ho, a.Wo, a.Hi, a.Wi = rowmap
     a.dW, a.lddw, a.dbias = ptr(dW), lddw if lddw is not None else N2, ptr(dbias)
     a.M, a.N1, a.N2 = M, N1, N2
-    check(lib().stes_wgrad(C.byref(a), stream_ptr()), "stes_wgrad")
+    check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")
+
+
+def _bn_bwd_args(D, raw1, M, Cc, *, mul=None, add=None, group=0, act=None, raw2=None,
+                 sums=None, coef=None, out=None):
+    a = BnBwdArgs()
+    a.D, a.mul, a.add, a.group = ptr(D), ptr(mul), ptr(add), group
+    if act is not None:
+        a.act_raw, a.act_scale, a.act_shift = ptr(act[0]), ptr(act[1]), ptr(act[2])
+    a.raw1, a.raw2 = ptr(raw1), ptr(raw2)
+    if sums is not None:
+        a.s_dy, a.s_dyr1 = ptr(sums[0]), ptr(sums[1])
+        a.s_dyr2 = ptr(sums[2]) if len(sums) > 2 else None
+    if coef is not None:
+        a.alpha, a.beta, a.delta = ptr(coef[0]), ptr(coef[1]), ptr(coef[2])
+    a.out = ptr(out)
+    a.M, a.C = M, Cc
+    return a
+
+
+def bn_bwd_reduce(D, raw1, M, Cc, sums, **kw):
+    a = _bn_bwd_args(D, raw1, M, Cc, sums=sums, **kw)
+    check(lib().stes_bn_bwd_reduce(C.byref(a), stream()), "stes_bn_bwd_reduce")
+
+
+def bn_bwd_apply(D, raw1, M, Cc, coef, out, **kw):
+    a = _bn_bwd_args(D, raw1, M, Cc, coef=coef, out=out, **kw)
+    check(lib().stes_bn_bwd_apply(C.byref(a), stream()), "stes_bn_bwd_apply")
+
+
+def gsm_geom(B, T, H, W, ldx, fold):
+    g = GsmGeom()
+    g.B, g.T, g.H, g.W, g.ldx, g.fold = B, T, H, W, ldx, fold
+    return g
+
+
+def gru_args(**kw):
+    a = GruArgs()
+    for k, v in kw.items():
+        setattr(a, k, ptr(v) if isinstance(v, torch.Tensor) else v)
+    return a

@@ -5,6 +5,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+_KEEP = []
+
+
+def dev(t):
+    # raw pointers go to the C-ABI: keep every device tensor alive until the module ends
+    t = t.detach().contiguous().cuda()
+    _KEEP.append(t)
+    return t
+
+
 def _bf(*shape, g, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
 
@@ -18,7 +28,7 @@ def test_gemm_plain(M, N, K):
     ref = A.float() @ W.float().t() + bias
     for out_dtype in (torch.bfloat16, torch.float32):
         C = torch.full((M, N), 7.0, dtype=out_dtype, device="cuda")
-        lib.gemm(A.cuda(), W.cuda(), C, M, N, K, bias=bias.cuda())
+        lib.gemm(dev(A), dev(W), C, M, N, K, bias=dev(bias))
         torch.cuda.synchronize()
         tol = 2e-2 if out_dtype == torch.bfloat16 else 2e-3
         torch.testing.assert_close(C.float().cpu(), ref, rtol=tol, atol=tol)
@@ -42,8 +52,8 @@ def test_gemm_prologue_stats_compact_and_rowmap():
     M = n_img * Ho * Wo
     C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
     s1 = torch.zeros(N, device="cuda"); s2 = torch.zeros(N, device="cuda")
-    lib.gemm(X.cuda(), W.cuda(), C, M, N, K, A0=G.cuda(), lda0=fold, k0=fold, scale=scale.cuda(), shift=shift.cuda(),
-             relu=True, gate=gate.cuda(), gate_group=Ho * Wo, rowmap=(2, Ho, Wo, Hi, Wi), stats=(s1, s2))
+    lib.gemm(dev(X), dev(W), C, M, N, K, A0=dev(G), lda0=fold, k0=fold, scale=dev(scale), shift=dev(shift),
+             relu=True, gate=dev(gate), gate_group=Ho * Wo, rowmap=(2, Ho, Wo, Hi, Wi), stats=(s1, s2))
     torch.cuda.synchronize()
     torch.testing.assert_close(C.float().cpu(), ref, rtol=2e-2, atol=2e-2)
     cb = C.float().cpu()
@@ -63,7 +73,7 @@ def test_wgrad(M, N1, N2):
     q = torch.relu(Q.float() * scale + shift).to(torch.bfloat16).float()
     ref = P[:, :N1].float().t() @ q
     dW = torch.zeros(N1, N2, device="cuda"); db = torch.zeros(N1, device="cuda")
-    lib.wgrad(P.cuda(), Q.cuda(), dW, M, N1, N2, ldp=ldp, scale=scale.cuda(), shift=shift.cuda(), relu=True, dbias=db)
+    lib.wgrad(dev(P), dev(Q), dW, M, N1, N2, ldp=ldp, scale=dev(scale), shift=dev(shift), relu=True, dbias=db)
     torch.cuda.synchronize()
     torch.testing.assert_close(dW.cpu(), ref, rtol=2e-3, atol=2e-3 * M ** 0.5)
     torch.testing.assert_close(db.cpu(), P[:, :N1].float().sum(0), rtol=1e-3, atol=1e-2)

@@ -1,0 +1,477 @@
+"""Each HIP kernel of libstes_hip against fp32 torch (CPU) on bf16-exact inputs, through the C-ABI.
+Tolerances: outputs stored as bf16 -> 1 bf16 ulp relative (8e-3) plus accumulation noise."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def bfr(*shape, g, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def nhwc(x):           # [N,C,H,W] -> [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def nchw(x, n, h, w):  # [N*H*W, C] -> [N,C,H,W]
+    return x.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+_KEEP = []
+
+
+def dev(t):
+    """Host tensor -> device tensor that stays alive until the test module is torn down (raw pointers are
+    handed to the C-ABI, so a temporary must not be returned to the caching allocator before the kernel ran)."""
+    t = t.detach().contiguous().cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 512:
+        torch.cuda.synchronize()
+        del _KEEP[:256]
+    return t
+
+
+def close(a, b, rtol=1e-2, atol=1e-2):
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("stride,H,W,C", [(1, 14, 14, 64), (2, 16, 12, 64), (1, 7, 7, 128), (2, 28, 28, 128), (2, 9, 7, 64)])
+def test_conv3x3g(stride, H, W, C):
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(3)
+    N = 3
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = bfr(N, C, H, W, g=g)
+    w = torch.randn(C, 16, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    wb = w.to(BF).float()
+    xin = torch.relu(x.float() * scale[None, :, None, None] + shift[None, :, None, None]).to(BF).float().requires_grad_(True)
+    wref = wb.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wref, stride=stride, padding=1, groups=C // 16)
+    gy = bfr(*ref.shape, g=g)
+    ref.backward(gy.float())
+
+    wp_f = torch.empty(C // 16 * 5 * 512, dtype=BF, device="cuda"); wp_d = torch.empty_like(wp_f)
+    lib.call("stes_pack_conv3x3g", lib.ptr(dev(w)), lib.ptr(wp_f), lib.ptr(wp_d), C // 16)
+    out = torch.zeros(N * Ho * Wo, C, dtype=BF, device="cuda")
+    s1 = torch.zeros(C, device="cuda"); s2 = torch.zeros(C, device="cuda")
+    xd = dev(nhwc(x))
+    lib.call("stes_conv3x3g_fwd", lib.ptr(xd), lib.ptr(wp_f), lib.ptr(out), lib.ptr(dev(scale)), lib.ptr(dev(shift)),
+             lib.ptr(s1), lib.ptr(s2), N, H, W, Ho, Wo, stride, C)
+    torch.cuda.synchronize()
+    close(nchw(out.cpu(), N, Ho, Wo), ref.detach(), 1e-2, 2e-2)
+    close(s1, out.float().sum(0), 1e-3, 1e-2)
+    close(s2, (out.float() ** 2).sum(0), 1e-3, 1e-2)
+    # dgrad
+    din = torch.zeros(N * H * W, C, dtype=BF, device="cuda")
+    gyd = dev(nhwc(gy))
+    lib.call("stes_conv3x3g_dgrad", lib.ptr(gyd), lib.ptr(wp_d), lib.ptr(din), N, H, W, Ho, Wo, stride, C)
+    torch.cuda.synchronize()
+    close(nchw(din.cpu(), N, H, W), xin.grad, 1e-2, 2e-2)
+    # wgrad
+    dw = torch.zeros(C, 16, 3, 3, device="cuda")
+    lib.call("stes_conv3x3g_wgrad", lib.ptr(gyd), lib.ptr(xd), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dw),
+             N, H, W, Ho, Wo, stride, C)
+    torch.cuda.synchronize()
+    close(dw, wref.grad, 1e-2, 2e-2 * math.sqrt(N * Ho * Wo))
+
+
+def test_im2col_stem():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(4)
+    N, H, W = 2, 12, 10
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g)
+    Ho, Wo = H // 2, W // 2
+    p = torch.empty(N * Ho * Wo, 32, dtype=BF, device="cuda")
+    lib.call("stes_im2col_stem", lib.ptr(dev(x)), lib.ptr(p), N, 3, H, W)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.to(BF).float(), w, stride=2, padding=1)
+    got = p.float().cpu()[:, :27] @ w.reshape(32, 27).t()
+    close(nchw(got, N, Ho, Wo), ref, 1e-4, 1e-4)
+    assert float(p.float().cpu()[:, 27:].abs().max()) == 0.0
+
+
+def test_bn_finalize_and_act_residual():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(5)
+    M, Cc = 500, 64
+    c = bfr(M, Cc, g=g); res = bfr(M, Cc, g=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm, rv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train()
+    ref = torch.relu(bn(c.float()) + res.float())
+    cf = c.float()
+    s1, s2 = dev(cf.sum(0)), dev((cf * cf).sum(0))
+    scale, shift, mean, inv = (torch.empty(Cc, device="cuda") for _ in range(4))
+    rmd, rvd = dev(rm.clone()), dev(rv.clone())
+    lib.call("stes_bn_finalize", lib.ptr(s1), lib.ptr(s2), float(M), lib.ptr(dev(gamma)), lib.ptr(dev(beta)), lib.ptr(rmd), lib.ptr(rvd),
+             0.1, 1e-5, 1, lib.ptr(scale), lib.ptr(shift), lib.ptr(mean), lib.ptr(inv), Cc)
+    out = torch.empty(M, Cc, dtype=BF, device="cuda")
+    st1 = torch.zeros(16, device="cuda"); st2 = torch.zeros(16, device="cuda")
+    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), lib.ptr(dev(res)), None, None, lib.ptr(out),
+             lib.ptr(st1), lib.ptr(st2), 16, M, Cc)
+    torch.cuda.synchronize()
+    close(out, ref.detach(), 1e-2, 1e-2)
+    close(rmd, bn.running_mean, 1e-5, 1e-5); close(rvd, bn.running_var, 1e-4, 1e-5)
+    close(st1, out.float()[:, :16].sum(0), 1e-4, 1e-3); close(st2, (out.float()[:, :16] ** 2).sum(0), 1e-4, 1e-3)
+    # eval mode
+    lib.call("stes_bn_finalize", None, None, 0.0, lib.ptr(dev(gamma)), lib.ptr(dev(beta)), lib.ptr(dev(rm)), lib.ptr(dev(rv)),
+             0.1, 1e-5, 0, lib.ptr(scale), lib.ptr(shift), None, None, Cc)
+    bn.eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+        ref = torch.relu(bn(c.float()))
+    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), None, None, None, lib.ptr(out), None, None, 0, M, Cc)
+    torch.cuda.synchronize()
+    close(out, ref, 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("Cc,R,HW", [(64, 8, 49), (320, 80, 30), (768, 192, 12)])
+def test_se(Cc, R, HW):
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(6)
+    N = 5
+    c2 = bfr(N * HW, Cc, g=g)
+    scale, shift = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    w1 = (torch.randn(R, Cc, generator=g) * Cc ** -0.5).requires_grad_(True); b1 = torch.randn(R, generator=g).requires_grad_(True)
+    w2 = (torch.randn(Cc, R, generator=g) * R ** -0.5).requires_grad_(True); b2 = torch.randn(Cc, generator=g).requires_grad_(True)
+    a = torch.relu(c2.float() * scale + shift).view(N, HW, Cc)
+    pooled = a.mean(1).detach().requires_grad_(True)
+    hidden = torch.relu(pooled @ w1.t() + b1)
+    gate = torch.sigmoid(hidden @ w2.t() + b2)
+    dgate = torch.randn(N, Cc, generator=g)
+    gate.backward(dgate)
+    pd = torch.empty(N, Cc, device="cuda")
+    lib.call("stes_chan_pool", lib.ptr(dev(c2)), lib.ptr(dev(scale)), lib.ptr(dev(shift)), None, lib.ptr(pd), None, N, HW, Cc, 1.0 / HW)
+    hd = torch.empty(N, R, device="cuda"); gd = torch.empty(N, Cc, device="cuda")
+    lib.call("stes_se_fc", lib.ptr(pd), lib.ptr(dev(w1)), lib.ptr(dev(b1)), lib.ptr(dev(w2)), lib.ptr(dev(b2)), lib.ptr(hd), lib.ptr(gd), N, Cc, R)
+    torch.cuda.synchronize()
+    close(pd, pooled, 1e-4, 1e-4); close(hd, hidden, 1e-4, 1e-4); close(gd, gate, 1e-4, 1e-4)
+    d2 = torch.empty(N, Cc, device="cuda"); d1 = torch.empty(N, R, device="cuda"); dp = torch.empty(N, Cc, device="cuda")
+    lib.call("stes_se_fc_bwd", lib.ptr(dev(dgate)), lib.ptr(gd), lib.ptr(hd), lib.ptr(dev(w1)), lib.ptr(dev(w2)), lib.ptr(d2), lib.ptr(d1),
+             lib.ptr(dp), 1.0, N, Cc, R)
+    dw2 = torch.zeros(Cc, R, device="cuda"); db2 = torch.zeros(Cc, device="cuda")
+    dw1 = torch.zeros(R, Cc, device="cuda"); db1 = torch.zeros(R, device="cuda")
+    lib.call("stes_f32_outer", lib.ptr(d2), lib.ptr(hd), lib.ptr(dw2), lib.ptr(db2), N, Cc, R)
+    lib.call("stes_f32_outer", lib.ptr(d1), lib.ptr(pd), lib.ptr(dw1), lib.ptr(db1), N, R, Cc)
+    torch.cuda.synchronize()
+    close(dp, pooled.grad, 1e-3, 1e-4)
+    close(dw2, w2.grad, 1e-3, 1e-4); close(db2, b2.grad, 1e-3, 1e-4)
+    close(dw1, w1.grad, 1e-3, 1e-4); close(db1, b1.grad, 1e-3, 1e-4)
+    # pooling with a multiplicand (SE backward reduction)
+    mul = bfr(N * HW, Cc, g=g)
+    lib.call("stes_chan_pool", lib.ptr(dev(c2)), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dev(mul)), lib.ptr(pd), None, N, HW, Cc, 1.0)
+    torch.cuda.synchronize()
+    close(pd, (a * mul.float().view(N, HW, Cc)).sum(1), 1e-3, 1e-3)
+
+
+def test_bn_backward_chain():
+    """dY = (D*mul + add) * relu-mask, then BatchNorm (training) backward: reduce -> finalize -> apply."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(7)
+    N, HW, Cc = 4, 25, 64
+    M = N * HW
+    raw = bfr(M, Cc, g=g).float().requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).requires_grad_(True); beta = torch.randn(Cc, generator=g).requires_grad_(True)
+    D = bfr(M, Cc, g=g); mul = torch.rand(N, Cc, generator=g); add = torch.randn(N, Cc, generator=g) * 0.1
+    mean = raw.mean(0); var = raw.var(0, unbiased=False); inv = (var + 1e-5).rsqrt()
+    yb = (raw - mean) * inv * gamma + beta
+    act = torch.relu(yb)
+    dA = (D.float().view(N, HW, Cc) * mul[:, None] + add[:, None]).reshape(M, Cc)
+    act.backward(dA)
+    scale = (gamma * inv).detach(); shift = (beta - mean * gamma * inv).detach()
+    sums = [torch.zeros(Cc, device="cuda") for _ in range(2)]
+    rawd = dev(raw.to(BF))
+    kw = dict(mul=dev(mul), add=dev(add), group=HW, act=(rawd, dev(scale), dev(shift)))
+    lib.bn_bwd_reduce(dev(D), rawd, M, Cc, sums, **kw)
+    coef = [torch.empty(Cc, device="cuda") for _ in range(3)]
+    dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    lib.call("stes_bn_bwd_finalize", lib.ptr(sums[0]), lib.ptr(sums[1]), lib.ptr(dev(mean)), lib.ptr(dev(inv)), lib.ptr(dev(gamma)),
+             float(M), lib.ptr(coef[0]), lib.ptr(coef[1]), lib.ptr(coef[2]), lib.ptr(dg), lib.ptr(db), Cc)
+    out = torch.empty(M, Cc, dtype=BF, device="cuda")
+    lib.bn_bwd_apply(dev(D), rawd, M, Cc, coef, out, **kw)
+    torch.cuda.synchronize()
+    close(dg, gamma.grad, 1e-3, 1e-3); close(db, beta.grad, 1e-3, 1e-3)
+    close(out, raw.grad, 1e-2, 1e-2)
+
+
+def test_block_in_grad_and_pool_bwd():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(8)
+    N, Hi, Wi, Cc, fold = 2, 6, 8, 32, 8
+    Ho, Wo = 3, 4
+    M = N * Hi * Wi
+    dY = bfr(M, Cc, g=g); dXf = bfr(M, fold, g=g); X = bfr(M, Cc, g=g); Dsc = bfr(N * Ho * Wo, Cc, g=g)
+    up = torch.zeros(N, Hi, Wi, Cc)
+    up[:, ::2, ::2] = Dsc.float().view(N, Ho, Wo, Cc)
+    ref = (torch.cat([dXf.float(), dY.float()[:, fold:]], 1) + up.view(M, Cc)) * (X.float() > 0)
+    out = torch.empty(M, Cc, dtype=BF, device="cuda")
+    d = dev
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc)
+    torch.cuda.synchronize()
+    close(out, ref, 1e-2, 1e-2)
+    ref = (torch.cat([dXf.float(), dY.float()[:, fold:]], 1) + dY.float()) * (X.float() > 0)
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc)
+    torch.cuda.synchronize()
+    close(out, ref, 1e-2, 1e-2)
+    da, db = torch.randn(N, Cc, generator=g), torch.randn(N, Cc, generator=g)
+    ref = ((da + db)[:, None] / (Hi * Wi) * (X.float().view(N, Hi * Wi, Cc) > 0)).reshape(M, Cc)
+    lib.call("stes_pool_bwd", lib.ptr(d(da)), lib.ptr(d(db)), lib.ptr(d(X)), lib.ptr(out), N, Hi * Wi, Cc)
+    torch.cuda.synchronize()
+    close(out, ref, 1e-2, 1e-3)
+
+
+def _gsm_run(z, mode, dev_bf=True):
+    """Run the GSM kernels on a golden case; returns (y, grads...) in the reference's NCHW layout."""
+    from spot_amd import lib
+    x = torch.from_numpy(z["x"]); gy = torch.from_numpy(z["gy"])
+    NT, fold, H, W = x.shape
+    T = int(z["T"]); B = NT // T
+    M = NT * H * W
+    d = lambda a: dev(torch.from_numpy(np.asarray(a)))
+    X = dev(nhwc(x).to(BF))                      # ldx = fold
+    geom = lib.gsm_geom(B, T, H, W, fold, fold)
+    s1 = torch.zeros(fold, device="cuda"); s2 = torch.zeros(fold, device="cuda")
+    lib.call("stes_col_stats", lib.ptr(X), fold, fold, M, lib.ptr(s1), lib.ptr(s2))
+    scale, shift, mean, inv = (torch.empty(fold, device="cuda") for _ in range(4))
+    rm, rv = d(z["rm0"]).clone(), d(z["rv0"]).clone()
+    lib.call("stes_bn_finalize", lib.ptr(s1), lib.ptr(s2), float(M), lib.ptr(d(z["bn_w"])), lib.ptr(d(z["bn_b"])), lib.ptr(rm), lib.ptr(rv),
+             0.1, 1e-5, int(mode == "train"), lib.ptr(scale), lib.ptr(shift), lib.ptr(mean), lib.ptr(inv), fold)
+    w3d, b3d = d(z["conv_w"]).contiguous(), d(z["conv_b"]).contiguous()
+    gate = torch.empty(M, 2, device="cuda")
+    lib.call("stes_gsm_gate", lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(b3d), lib.ptr(gate), C.byref(geom))
+    G = torch.empty(M, fold, dtype=BF, device="cuda")
+    lib.call("stes_gsm_shift", lib.ptr(X), lib.ptr(gate), lib.ptr(G), C.byref(geom))
+    res = {"y": nchw(G.float().cpu(), NT, H, W), "rm": rm.cpu(), "rv": rv.cpu()}
+    if mode == "train":
+        dG = dev(nhwc(gy).to(BF))
+        dpre = torch.empty(M, 2, device="cuda")
+        lib.call("stes_gsm_bwd_gate", lib.ptr(dG), fold, lib.ptr(X), lib.ptr(gate), lib.ptr(dpre), C.byref(geom))
+        dw = torch.zeros_like(w3d); db = torch.zeros(2, device="cuda")
+        lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
+        sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
+        lib.call("stes_gsm_bwd_bnreduce", lib.ptr(dpre), lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(sd), lib.ptr(sdx), C.byref(geom))
+        coef = [torch.empty(fold, device="cuda") for _ in range(3)]
+        dgam = torch.zeros(fold, device="cuda"); dbet = torch.zeros(fold, device="cuda")
+        lib.call("stes_bn_bwd_finalize", lib.ptr(sd), lib.ptr(sdx), lib.ptr(mean), lib.ptr(inv), lib.ptr(d(z["bn_w"])), float(M),
+                 lib.ptr(coef[0]), lib.ptr(coef[1]), lib.ptr(coef[2]), lib.ptr(dgam), lib.ptr(dbet), fold)
+        dXf = torch.empty(M, fold, dtype=BF, device="cuda")
+        lib.call("stes_gsm_bwd_dx", lib.ptr(dG), fold, lib.ptr(X), lib.ptr(gate), lib.ptr(dpre), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d),
+                 lib.ptr(coef[0]), lib.ptr(coef[1]), lib.ptr(coef[2]), lib.ptr(dXf), C.byref(geom))
+        res.update(gx=nchw(dXf.float().cpu(), NT, H, W), dw=dw.cpu(), db=db.cpu(), dgam=dgam.cpu(), dbet=dbet.cpu())
+    torch.cuda.synchronize()
+    return res
+
+
+@pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_gsm_vs_reference_golden(golden, fold, mode):
+    """Inputs of the golden vectors rounded to bf16 (the kernels' storage type); expected values are the
+    reference's fp32 outputs -> tolerance 2 bf16 ulp + the input rounding."""
+    z = golden(f"gsm_f{fold}_{mode}_rand")
+    r = _gsm_run(z, mode)
+    close(r["y"], torch.from_numpy(z["y"]), 2e-2, 3e-2)
+    if mode == "train":
+        close(r["rm"], torch.from_numpy(z["rm1"]), 1e-2, 2e-3); close(r["rv"], torch.from_numpy(z["rv1"]), 1e-2, 2e-3)
+        gx, gxr = r["gx"], torch.from_numpy(z["gx"])
+        assert float((gx - gxr).norm() / gxr.norm()) < 2e-2
+        for k, kr in (("dw", "g_conv_w"), ("db", "g_conv_b"), ("dgam", "g_bn_w"), ("dbet", "g_bn_b")):
+            a, b = r[k].flatten(), torch.from_numpy(z[kr]).flatten()
+            assert float((a - b).norm() / (b.norm() + 1e-6)) < 3e-2, k
+
+
+@pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
+def test_gsm_zero_gate_shift_indexing_bit_exact(golden, fold):
+    """conv3D = 0 (the reference's init): output is exactly the within-group channel interleave of the bf16 input."""
+    z = golden(f"gsm_f{fold}_eval_zero")
+    r = _gsm_run(z, "eval")
+    xb = torch.from_numpy(z["x"]).to(BF).float()
+    yref = torch.from_numpy(z["y"])
+    # reference output is a pure permutation of its input, so the bf16 version must be the same permutation of the bf16 input
+    half, quarter = fold // 2, fold // 4
+    dest = [(c // half) * half + 2 * ((c % half) % quarter) + (c % half) // quarter for c in range(fold)]
+    assert torch.equal(yref[:, dest], torch.from_numpy(z["x"]))
+    assert torch.equal(r["y"][:, dest], xb)
+
+
+@pytest.mark.parametrize("c", [32, 64, 320])
+def test_tsm_bit_exact(golden, c):
+    from spot_amd import lib
+    z = golden(f"tsm_c{c}")
+    x = torch.from_numpy(z["x"]).to(BF); T = int(z["T"])
+    NT, Cc, H, W = x.shape
+    X = dev(nhwc(x.float()).to(BF)); out = torch.empty_like(X)
+    lib.call("stes_tsm_shift", lib.ptr(X), lib.ptr(out), Cc // 8, Cc, NT // T, T, H, W, 0)
+    gy = torch.from_numpy(z["gy"]).to(BF)
+    GY = dev(nhwc(gy.float()).to(BF)); gx = torch.empty_like(GY)
+    lib.call("stes_tsm_shift", lib.ptr(GY), lib.ptr(gx), Cc // 8, Cc, NT // T, T, H, W, 1)
+    torch.cuda.synchronize()
+    from oracle import stes_oracle as O
+    assert torch.equal(nchw(out.float().cpu(), NT, H, W), O.tsm_shift(x.float(), T, 8))
+    xr = x.float().requires_grad_(True)
+    O.tsm_shift(xr, T, 8).backward(gy.float())
+    assert torch.equal(nchw(gx.float().cpu(), NT, H, W), xr.grad)
+
+
+def _pack_gru(sd, l, H):
+    sfx = ("", "_reverse")
+    wih = torch.cat([sd[f"_gru.weight_ih_l{l}{s}"] for s in sfx], 0)
+    bih = torch.cat([sd[f"_gru.bias_ih_l{l}{s}"] for s in sfx], 0)
+    whh = torch.stack([sd[f"_gru.weight_hh_l{l}{s}"] for s in sfx], 0)
+    bhh = torch.stack([sd[f"_gru.bias_hh_l{l}{s}"] for s in sfx], 0)
+    return wih, bih, whh, bhh
+
+
+def test_gru_layer_vs_reference_golden(golden):
+    """One bidirectional GRU layer forward + BPTT against torch.nn.GRU as run by the reference's GRUPrediction."""
+    from spot_amd import lib
+    z = golden("gru_L1")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    x = torch.from_numpy(z["x"])
+    B, T, I = x.shape
+    H = 48
+    # hidden size 48 is not a multiple of 32: embed into H' = 64 with zero padding (zero weights keep extra units at 0)
+    Hp = 64
+    wih, bih, whh, bhh = _pack_gru(sd, 0, H)
+
+    def pad_gates(w, cols=None):   # [.., 3H, X] -> [.., 3H', X']
+        shp = list(w.shape)
+        lead = shp[:-2] if w.dim() > 2 else []
+        w3 = w.reshape(*lead, 3, H, shp[-1])
+        out = torch.zeros(*lead, 3, Hp, cols or shp[-1])
+        out[..., :H, :shp[-1]] = w3
+        return out.reshape(*lead, 3 * Hp, cols or shp[-1])
+
+    Ip = 64
+    xp = torch.zeros(B, T, Ip); xp[..., :I] = x
+    wih_p = torch.cat([pad_gates(wih[:3 * H], Ip), pad_gates(wih[3 * H:], Ip)], 0)            # [6H', I']
+    bih_p = torch.cat([pad_gates(bih[:3 * H, None]).flatten(), pad_gates(bih[3 * H:, None]).flatten()])
+    whh_p = torch.stack([pad_gates(whh[d], Hp) for d in range(2)])                               # [2, 3H', H']
+    bhh_p = torch.stack([pad_gates(bhh[d][:, None]).flatten() for d in range(2)])
+    M = B * T
+    gi = torch.empty(M, 6 * Hp, dtype=BF, device="cuda")
+    lib.gemm(dev(xp.reshape(M, Ip).to(BF)), dev(wih_p.to(BF)), gi, M, 6 * Hp, Ip, bias=dev(bih_p))
+    y = torch.zeros(B, T, 2 * Hp, dtype=BF, device="cuda")
+    hstate = torch.zeros(2, 2, B, Hp, device="cuda"); saved = torch.zeros(2, T, B, 5, Hp, device="cuda")
+    hprev = torch.zeros(2, T, B, Hp, dtype=BF, device="cuda")
+    whh_d = dev(whh_p.to(BF)); whhT_d = dev(whh_p.transpose(1, 2).to(BF)); bhh_d = dev(bhh_p)
+    a = lib.gru_args(gi=gi, whh=whh_d, whhT=whhT_d, bhh=bhh_d, y=y, hstate=hstate, saved=saved, hprev_bf=hprev, B=B, T=T, H=Hp)
+    lib.check(lib.lib().stes_gru_forward(C.byref(a), lib.stream()), "gru fwd")
+    torch.cuda.synchronize()
+    ref_gru = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
+    ref_gru.load_state_dict({k[5:]: v for k, v in sd.items() if k.startswith("_gru.")})
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref_gru(xr)
+    yk = y.float().cpu()
+    got = torch.cat([yk[..., :H], yk[..., Hp:Hp + H]], -1)
+    close(got, yr.detach(), 2e-2, 2e-2)
+    assert float(yk[..., H:Hp].abs().max()) == 0.0
+    # backward
+    g = torch.Generator().manual_seed(1)
+    dy = torch.randn(B, T, 2 * H, generator=g)
+    yr.backward(dy)
+    dyp = torch.zeros(B, T, 2 * Hp); dyp[..., :H] = dy[..., :H]; dyp[..., Hp:Hp + H] = dy[..., H:]
+    dgi = torch.zeros(M, 6 * Hp, dtype=BF, device="cuda"); dgh = torch.zeros(2, T, B, 3 * Hp, dtype=BF, device="cuda")
+    dhs = torch.zeros(2, 2, B, Hp, device="cuda")
+    a = lib.gru_args(gi=gi, whh=whh_d, whhT=whhT_d, bhh=bhh_d, y=y, hstate=hstate, saved=saved, hprev_bf=hprev,
+                     dy=dev(dyp), ld_dy=2 * Hp, dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=Hp)
+    lib.check(lib.lib().stes_gru_backward(C.byref(a), lib.stream()), "gru bwd")
+    dx = torch.empty(M, Ip, device="cuda")
+    lib.gemm(dgi, dev(wih_p.t().to(BF)), dx, M, Ip, 6 * Hp)
+    dwhh = torch.zeros(2, 3 * Hp, Hp, device="cuda"); dbhh = torch.zeros(2, 3 * Hp, device="cuda")
+    for d in range(2):
+        lib.wgrad(dgh[d], hprev[d], dwhh[d], T * B, 3 * Hp, Hp, dbias=dbhh[d])
+    torch.cuda.synchronize()
+    close(dx.cpu()[:, :I].reshape(B, T, I), xr.grad, 3e-2, 3e-2)
+    for d, s in enumerate(("", "_reverse")):
+        ref_w = getattr(ref_gru, f"weight_hh_l0{s}").grad
+        got_w = dwhh[d].cpu().reshape(3, Hp, Hp)[:, :H, :H].reshape(3 * H, H)
+        assert float((got_w - ref_w).norm() / ref_w.norm()) < 3e-2
+        ref_b = getattr(ref_gru, f"bias_hh_l0{s}").grad
+        got_b = dbhh[d].cpu().reshape(3, Hp)[:, :H].reshape(-1)
+        assert float((got_b - ref_b).norm() / ref_b.norm()) < 3e-2
+
+
+def test_mingru_scan():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(2)
+    B, T, H = 3, 9, 40
+    pre = bfr(B, T, 2 * H, g=g)
+    pr = pre.float().requires_grad_(True)
+    z = torch.sigmoid(pr[..., :H]); cand = pr[..., H:]
+    h = torch.zeros(B, H); hs = []
+    for t in range(T):
+        h = (1 - z[:, t]) * h + z[:, t] * cand[:, t]
+        hs.append(h)
+    hs = torch.stack(hs, 1)
+    dh = torch.randn(B, T, H, generator=g)
+    hs.backward(dh)
+    hd = torch.empty(B, T, H, dtype=BF, device="cuda")
+    lib.call("stes_mingru_scan_fwd", lib.ptr(dev(pre)), lib.ptr(hd), B, T, H)
+    dpre = torch.empty(B, T, 2 * H, dtype=BF, device="cuda")
+    lib.call("stes_mingru_scan_bwd", lib.ptr(dev(pre)), lib.ptr(hd), lib.ptr(dev(dh)), H, lib.ptr(dpre), B, T, H)
+    torch.cuda.synchronize()
+    close(hd, hs.detach(), 1e-2, 1e-2)
+    close(dpre, pr.grad, 3e-2, 2e-2)
+
+
+def test_loss_and_adamw_vs_reference_golden(golden):
+    from spot_amd import lib
+    from oracle import stes_oracle as O
+    g = torch.Generator().manual_seed(3)
+    M, Cc = 200, 7
+    logits = torch.randn(M, Cc, generator=g).requires_grad_(True); loc = torch.randn(M, 2, generator=g).requires_grad_(True)
+    label = torch.randint(0, Cc, (M,), generator=g); label[:50] = 0
+    xy = torch.rand(M, 2, generator=g)
+    loss, lc, ll = O.stes_loss(logits.view(1, M, Cc), loc.view(1, M, 2), label, xy, Cc)
+    loss.backward()
+    out = torch.zeros(5, device="cuda")
+    dl = torch.empty(M, 8, dtype=BF, device="cuda"); dloc = torch.empty(M, 8, dtype=BF, device="cuda")
+    d = dev
+    lib.call("stes_loss", lib.ptr(d(logits)), Cc, lib.ptr(d(loc)), 2, lib.ptr(d(label)), lib.ptr(d(xy)), M, Cc, 5.0, 1.0, None,
+             lib.ptr(out), lib.ptr(dl), lib.ptr(dloc))
+    torch.cuda.synchronize()
+    close(out[:3], torch.stack([loss, lc, ll]).detach(), 1e-5, 1e-5)
+    close(dl[:, :Cc], logits.grad, 1e-2, 1e-5); close(dloc[:, :2], loc.grad, 1e-2, 1e-5)
+    assert float(dl[:, Cc:].float().abs().max()) == 0 and float(dloc[:, 2:].float().abs().max()) == 0
+    # AdamW against torch.optim.AdamW (the reference's optimiser) over 3 steps
+    n = 1000
+    p = torch.randn(n, generator=g); p0 = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p0], lr=1e-2)
+    pd = dev(p); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        p0.grad = gr.clone(); opt.step()
+        lib.call("stes_adamw", lib.ptr(pd), lib.ptr(dev(gr)), lib.ptr(m), lib.ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step, 1.0)
+    torch.cuda.synchronize()
+    close(pd, p0.detach(), 1e-5, 1e-6)
+
+
+def test_cast_and_dropout():
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(7, 20, generator=g)
+    a = torch.empty(8, 24, dtype=BF, device="cuda"); b = torch.empty(24, 8, dtype=BF, device="cuda")
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(a), 7, 20, 24, 8, 0)
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(b), 7, 20, 8, 24, 1)
+    x = dev(bfr(4096, g=g)); out = torch.empty_like(x); mask = torch.empty_like(x)
+    lib.call("stes_dropout", lib.ptr(x), lib.ptr(out), lib.ptr(mask), 4096, 0.5, 1234)
+    torch.cuda.synchronize()
+    ref = torch.zeros(8, 24); ref[:7, :20] = w.to(BF).float()
+    assert torch.equal(a.float().cpu(), ref)
+    assert torch.equal(b.float().cpu()[:20, :7], w.to(BF).float().t()) and float(b.float().cpu()[20:].abs().max()) == 0
+    mk = mask.float().cpu()
+    assert set(mk.unique().tolist()) <= {0.0, 2.0} and 0.4 < float((mk > 0).float().mean()) < 0.6
+    assert torch.equal(out.float().cpu(), (x.float().cpu() * mk).to(BF).float())
