@@ -476,16 +476,25 @@ class Impl(nn.Module):
         return {"im_feat": ev.flip(1) if self.time_backward else ev, "loc_feat": loc, "cnn_feat": im}
 
 
-def randomize_(model: nn.Module, seed: int = 0, gsm_std: float = 0.1) -> None:
+def randomize_(model: nn.Module, seed: int = 0, gsm_gain: float = 1.0) -> None:
     """Seeded synthetic weights (no pretrained weights exist offline).  GSM conv3D
-    is drawn N(0, gsm_std) because its zero init (model/shift.py:89-90) makes the gate
-    trivially zero; BN affine and running stats are perturbed so that every term of
-    the normalisation is exercised."""
+    is drawn N(0, gsm_gain / sqrt(fan_in)) because its zero init (model/shift.py:89-90)
+    makes the gate trivially zero; the fan-in scaling keeps the gate pre-activation O(1)
+    at every fold width (a fixed std saturates tanh in the wide blocks and makes the
+    network chaotic: fp32 and bf16 runs of the SAME code then differ by > 5 %).  BN affine
+    and running stats are perturbed so that every term of the normalisation is exercised."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if "conv3D" in name:
-                p.copy_(torch.randn(p.shape, generator=g) * gsm_std)
+            if "conv3D.weight" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * gsm_gain / math.sqrt(p[0].numel()))
+            elif "conv3D.bias" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif name.endswith("conv3.bn.weight"):
+                # timm zero-initialises the last BatchNorm of every residual branch; a small non-zero gain keeps the
+                # branch live while the random network stays well conditioned (gain 1 makes every block amplify a
+                # perturbation ~1.3x in training mode: fp32 and bf16 runs of the same code then differ by > 20 %)
+                p.copy_(0.25 * (1.0 + 0.2 * torch.randn(p.shape, generator=g)))
             elif name.endswith("bn.weight"):
                 p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
             elif name.endswith("bn.bias"):
@@ -533,7 +542,7 @@ def train_step(model: Impl, opt, frame, label, xy, num_classes, fg_weight=5.0):
     loss.backward()
     opt.step()
     opt.zero_grad()
-    return float(loss), float(lc), float(ll)
+    return float(loss.detach()), float(lc.detach()), float(ll.detach())
 
 
 def predict(model: Impl, seq):

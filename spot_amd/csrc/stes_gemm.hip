@@ -436,7 +436,8 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
 extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     STES_CHECK(a && a->P && a->Q && a->dW, STES_ERR_ARG, "stes_wgrad: null pointer");
     STES_CHECK(a->M > 0 && a->N1 > 0 && a->N2 > 0, STES_ERR_ARG, "stes_wgrad: empty shape");
-    STES_CHECK(a->N2 % 8 == 0 && a->ldp % 8 == 0 && a->ldq % 8 == 0, STES_ERR_ARG, "stes_wgrad: N2, ldp, ldq must be multiples of 8");
+    STES_CHECK(a->ldp % 8 == 0 && a->ldq % 8 == 0 && a->ldq >= (a->N2 + 7) / 8 * 8, STES_ERR_ARG, "stes_wgrad: ldp, ldq must be multiples of 8 and cover N2 rounded up to 8");
+    STES_CHECK(a->N2 % 8 == 0 || (!a->q_scale && !a->q_gate), STES_ERR_ARG, "stes_wgrad: a prologue needs N2 % 8 == 0");
     STES_CHECK(a->k0 == 0 || (a->Q0 && a->k0 % 8 == 0 && a->ldq0 % 8 == 0), STES_ERR_ARG, "stes_wgrad: bad compact source");
     STES_CHECK(a->ldp >= (a->N1 + 7) / 8 * 8, STES_ERR_ARG, "stes_wgrad: ldp must cover N1 rounded up to 8 (pad the operand)");
     const bool big = a->N1 > 64 && a->N2 > 64;

@@ -1,0 +1,701 @@
+"""Host-side executor of the STES hot path on one MI355X.
+
+Walks the parameter tree of `E2EModel.Impl` (RegNet-Y + gated/plain temporal shift + GRU/minGRU
+head + location MLP; reference train_e2e_spatial.py:232-455) once, lays every learnable tensor
+out in ONE flat fp32 buffer (with a twin buffer for gradients, so the data-parallel all-reduce and
+the fused AdamW see contiguous memory), keeps bf16 MFMA-ready copies of the weights, and runs the
+forward / backward pass as a fixed sequence of libstes_hip kernel launches on the current HIP stream.
+
+Activations are NHWC bf16 ([frames*H*W][C]); accumulation, BatchNorm statistics, the GRU state,
+losses and optimizer state are fp32.  Nothing here computes on the host or through torch operators:
+torch supplies device memory, streams and (in spot_amd.dp) the RCCL process group.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib
+from .model.modules import FCPrediction, GRUPrediction
+from .model.min_gru import MinRNNPredictor
+from .model.shift import GatedShift, TemporalShift
+from .regnet import ConvBnAct
+
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class BN:
+    """One BatchNorm site: folded scale/shift for the consumer's prologue, saved batch statistics, the
+    backward coefficients, and four accumulators in the per-step zeroed statistics arena."""
+
+    def __init__(self, eng, mod):
+        self.mod, self.C = mod, mod.num_features
+        Cc = self.C
+        self.scale, self.shift, self.mean, self.inv, self.alpha, self.beta, self.delta = eng.f32_block(7, Cc)
+        self.sum, self.sumsq, self.s_dy, self.s_dyr = eng.stats_block(4, Cc)
+        self.eng = eng
+
+    def finalize(self, count, training):
+        m = self.mod
+        lib.call("stes_bn_finalize", lib.ptr(self.sum), lib.ptr(self.sumsq), float(count), lib.ptr(m.weight), lib.ptr(m.bias),
+                 lib.ptr(m.running_mean), lib.ptr(m.running_var), float(m.momentum), float(m.eps), int(training),
+                 lib.ptr(self.scale), lib.ptr(self.shift), lib.ptr(self.mean), lib.ptr(self.inv), self.C)
+
+    def bwd_finalize(self, count, s_dy=None):
+        g = self.eng.grad
+        lib.call("stes_bn_bwd_finalize", lib.ptr(s_dy if s_dy is not None else self.s_dy), lib.ptr(self.s_dyr), lib.ptr(self.mean),
+                 lib.ptr(self.inv), lib.ptr(self.mod.weight), float(count), lib.ptr(self.alpha), lib.ptr(self.beta),
+                 lib.ptr(self.delta), lib.ptr(g(self.mod.weight)), lib.ptr(g(self.mod.bias)), self.C)
+
+    @property
+    def coef(self):
+        return (self.alpha, self.beta, self.delta)
+
+
+class Linear:
+    """nn.Linear / 1x1 conv weight with its bf16 copy [N][K] and transposed copy [K][N8]."""
+
+    def __init__(self, eng, weight, bias=None, n=None, k=None, kp=None):
+        self.w, self.b = weight, bias
+        self.N = n if n is not None else weight.shape[0]
+        self.K = k if k is not None else weight[0].numel()
+        self.Kp = kp if kp is not None else _rup(self.K, 8)           # padded K (stem: 9*Cin -> 32)
+        self.Np = _rup(self.N, 8)
+        self.w_bf = eng.bf16(self.N, self.Kp)
+        self.wT_bf = eng.bf16(self.Kp, self.Np)
+        eng.casts.append((weight, self.w_bf, self.N, self.K, self.Kp, self.N, 0))
+        eng.casts.append((weight, self.wT_bf, self.N, self.K, self.Np, self.Kp, 1))
+
+
+class Block:
+    def __init__(self, eng, blk, name):
+        self.eng, self.name = eng, name
+        c1 = blk.conv1
+        self.kind = "gsm" if isinstance(c1, GatedShift) else ("tsm" if isinstance(c1, TemporalShift) else "none")
+        conv1 = c1.net if self.kind != "none" else c1
+        self.cin, self.cmid, self.stride = conv1.conv.in_channels, conv1.conv.out_channels, blk.conv2.conv.stride[0]
+        self.cout = blk.conv3.conv.out_channels
+        if blk.conv2.conv.in_channels // blk.conv2.conv.groups != 16 or self.cmid % 64:
+            raise NotImplementedError("grouped 3x3 conv kernel is built for group width 16 and channels % 64 == 0 (regnety_008)")
+        self.l1 = Linear(eng, conv1.conv.weight)
+        self.l3 = Linear(eng, blk.conv3.conv.weight)
+        self.bn1, self.bn2, self.bn3 = BN(eng, conv1.bn), BN(eng, blk.conv2.bn), BN(eng, blk.conv3.bn)
+        self.w2 = blk.conv2.conv.weight
+        G = self.cmid // 16
+        self.wp2_f, self.wp2_d = eng.bf16(G * 5 * 512), eng.bf16(G * 5 * 512)
+        eng.packs.append((self.w2, self.wp2_f, self.wp2_d, G))
+        self.se = blk.se
+        self.rd = blk.se.fc1.out_channels
+        self.down = isinstance(blk.downsample, ConvBnAct)
+        if self.down:
+            self.ld = Linear(eng, blk.downsample.conv.weight)
+            self.bnd = BN(eng, blk.downsample.bn)
+        self.fold = 0
+        if self.kind == "gsm":
+            self.fold = c1.fold_dim
+            if self.fold % 8:
+                raise NotImplementedError("gated shift kernels need fold % 8 == 0")
+            self.gsm = c1.gsm
+            self.bng = BN(eng, c1.gsm.bn)
+        elif self.kind == "tsm":
+            self.tsm_fold = self.cin // c1.fold_div
+
+    # ------------------------------------------------------------------ shapes / buffers
+    def plan(self, N, Hi, Wi, T, train):
+        e = self.eng
+        self.N, self.Hi, self.Wi, self.T = N, Hi, Wi, T
+        s = self.stride
+        self.Ho, self.Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
+        self.Mi, self.Mo = N * Hi * Wi, N * self.Ho * self.Wo
+        a = e.act
+        nm = self.name
+        if self.kind == "gsm":
+            self.G = a(nm + ".G", self.Mi * self.fold, BF)
+            self.gate = a(nm + ".gate", self.Mi * 2, F32)
+        elif self.kind == "tsm":
+            self.Xs = a(nm + ".Xs", self.Mi * self.cin, BF)
+        self.c1 = a(nm + ".c1", self.Mi * self.cmid, BF)
+        self.c2 = a(nm + ".c2", self.Mo * self.cmid, BF)
+        self.c3 = a(nm + ".c3", self.Mo * self.cout, BF)
+        self.pooled = a(nm + ".pooled", N * self.cmid, F32)
+        self.hidden = a(nm + ".hidden", N * self.rd, F32)
+        self.segate = a(nm + ".segate", N * self.cmid, F32)
+        if self.down:
+            self.sc = a(nm + ".sc", self.Mo * self.cout, BF)
+        self.out = a(nm + ".out", self.Mo * self.cout, BF)
+        return self.Ho, self.Wo
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, X, train, next_fold, next_stats):
+        e = self.eng
+        p = lib.ptr
+        Mi, Mo, cin, cmid, cout = self.Mi, self.Mo, self.cin, self.cmid, self.cout
+        st = (lambda bn: (bn.sum, bn.sumsq)) if train else (lambda bn: None)
+        self.X = X
+        a_src, a0, k0 = X, None, 0
+        if self.kind == "gsm":
+            geom = lib.gsm_geom(self.N // self.T, self.T, self.Hi, self.Wi, cin, self.fold)
+            self.geom = geom
+            self.bng.finalize(Mi, train)
+            w3d, b3d = self.gsm.conv3D.weight, self.gsm.conv3D.bias
+            lib.call("stes_gsm_gate", p(X), p(self.bng.scale), p(self.bng.shift), p(w3d), p(b3d), p(self.gate), C.byref(geom))
+            lib.call("stes_gsm_shift", p(X), p(self.gate), p(self.G), C.byref(geom))
+            a0, k0 = self.G, self.fold
+        elif self.kind == "tsm":
+            lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
+            a_src = self.Xs
+        self.a_src = a_src
+        lib.gemm(a_src, self.l1.w_bf, self.c1, Mi, cmid, cin, A0=a0, lda0=k0, k0=k0, stats=st(self.bn1))
+        self.bn1.finalize(Mi, train)
+        s2 = st(self.bn2)
+        lib.call("stes_conv3x3g_fwd", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),
+                 p(s2[0]) if s2 else None, p(s2[1]) if s2 else None, self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
+        self.bn2.finalize(Mo, train)
+        HWo = self.Ho * self.Wo
+        lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, p(self.pooled), None, self.N, HWo, cmid, 1.0 / HWo)
+        se = self.se
+        lib.call("stes_se_fc", p(self.pooled), p(se.fc1.weight), p(se.fc1.bias), p(se.fc2.weight), p(se.fc2.bias), p(self.hidden),
+                 p(self.segate), self.N, cmid, self.rd)
+        lib.gemm(self.c2, self.l3.w_bf, self.c3, Mo, cout, cmid, scale=self.bn2.scale, shift=self.bn2.shift, relu=True,
+                 gate=self.segate, gate_group=HWo, stats=st(self.bn3))
+        self.bn3.finalize(Mo, train)
+        ns = next_stats if train else None
+        if self.down:
+            rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
+            lib.gemm(a_src, self.ld.w_bf, self.sc, Mo, cout, cin, rowmap=rowmap, stats=st(self.bnd))
+            self.bnd.finalize(Mo, train)
+            res, rs, rb = self.sc, self.bnd.scale, self.bnd.shift
+        else:
+            res, rs, rb = a_src, None, None
+        lib.call("stes_bn_act_residual", p(self.c3), p(self.bn3.scale), p(self.bn3.shift), p(res), p(rs), p(rb), p(self.out),
+                 p(ns[0]) if ns else None, p(ns[1]) if ns else None, next_fold if ns else 0, Mo, cout)
+        return self.out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dZ):
+        """dZ: gradient w.r.t. this block's output, already masked by (out > 0).  Returns the masked gradient
+        w.r.t. the block input."""
+        e = self.eng
+        p, g, sc = lib.ptr, e.grad, e.scratch
+        Mi, Mo, cin, cmid, cout = self.Mi, self.Mo, self.cin, self.cmid, self.cout
+        HWo = self.Ho * self.Wo
+        X, a_src = self.X, self.a_src
+        bn1, bn2, bn3 = self.bn1, self.bn2, self.bn3
+        # --- conv3.bn (+ shortcut bn) backward
+        sums = [bn3.s_dy, bn3.s_dyr] + ([self.bnd.s_dyr] if self.down else [])
+        lib.bn_bwd_reduce(dZ, self.c3, Mo, cout, sums, raw2=self.sc if self.down else None)
+        bn3.bwd_finalize(Mo)
+        dc3 = sc("dc3", Mo * cout)
+        lib.bn_bwd_apply(dZ, self.c3, Mo, cout, bn3.coef, dc3)
+        # --- conv3 (1x1): weight and input gradients
+        lib.wgrad(dc3, self.c2, g(self.l3.w), Mo, cout, cmid, scale=bn2.scale, shift=bn2.shift, relu=True, gate=self.segate,
+                  gate_group=HWo)
+        dA3 = sc("dA3", Mo * cmid)
+        lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
+        # --- squeeze-excite backward
+        dgate = sc("se.dgate", self.N * cmid, F32)
+        lib.call("stes_chan_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(dgate), None, self.N, HWo, cmid, 1.0)
+        dpre2, dpre1, dpool = sc("se.dpre2", self.N * cmid, F32), sc("se.dpre1", self.N * self.rd, F32), sc("se.dpool", self.N * cmid, F32)
+        se = self.se
+        lib.call("stes_se_fc_bwd", p(dgate), p(self.segate), p(self.hidden), p(se.fc1.weight), p(se.fc2.weight), p(dpre2), p(dpre1),
+                 p(dpool), 1.0 / HWo, self.N, cmid, self.rd)
+        lib.call("stes_f32_outer", p(dpre2), p(self.hidden), p(g(se.fc2.weight)), p(g(se.fc2.bias)), self.N, cmid, self.rd)
+        lib.call("stes_f32_outer", p(dpre1), p(self.pooled), p(g(se.fc1.weight)), p(g(se.fc1.bias)), self.N, self.rd, cmid)
+        # --- conv2.bn backward: dY2 = (dA3*gate + dpool) * [bn2(c2) > 0]
+        kw2 = dict(mul=self.segate, add=dpool, group=HWo, act=(self.c2, bn2.scale, bn2.shift))
+        lib.bn_bwd_reduce(dA3, self.c2, Mo, cmid, [bn2.s_dy, bn2.s_dyr], **kw2)
+        bn2.bwd_finalize(Mo)
+        dc2 = sc("dc2", Mo * cmid)
+        lib.bn_bwd_apply(dA3, self.c2, Mo, cmid, bn2.coef, dc2, **kw2)
+        # --- grouped 3x3 conv
+        geo = (self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
+        lib.call("stes_conv3x3g_wgrad", p(dc2), p(self.c1), p(bn1.scale), p(bn1.shift), p(g(self.w2)), *geo)
+        dA2 = sc("dA2", Mi * cmid)
+        lib.call("stes_conv3x3g_dgrad", p(dc2), p(self.wp2_d), p(dA2), *geo)
+        # --- conv1.bn backward: dY1 = dA2 * [bn1(c1) > 0]
+        kw1 = dict(act=(self.c1, bn1.scale, bn1.shift))
+        lib.bn_bwd_reduce(dA2, self.c1, Mi, cmid, [bn1.s_dy, bn1.s_dyr], **kw1)
+        bn1.bwd_finalize(Mi)
+        dc1 = sc("dc1", Mi * cmid)
+        lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1, **kw1)
+        # --- conv1 (1x1)
+        q0, k0 = (self.G, self.fold) if self.kind == "gsm" else (None, 0)
+        lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0)
+        dY1 = sc("dY1", Mi * cin)
+        lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, ldw=self.l1.Np)
+        dXf = None
+        if self.kind == "gsm":
+            gs, bng, geom = self.gsm, self.bng, self.geom
+            dpre = sc("gsm.dpre", Mi * 2, F32)
+            lib.call("stes_gsm_bwd_gate", p(dY1), cin, p(X), p(self.gate), p(dpre), C.byref(geom))
+            lib.call("stes_gsm_bwd_wgrad", p(dpre), p(X), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), C.byref(geom))
+            lib.call("stes_gsm_bwd_bnreduce", p(dpre), p(X), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(bng.s_dy), p(bng.s_dyr), C.byref(geom))
+            bng.bwd_finalize(Mi)
+            dXf = sc("gsm.dXf", Mi * self.fold)
+            lib.call("stes_gsm_bwd_dx", p(dY1), cin, p(X), p(self.gate), p(dpre), p(bng.scale), p(bng.shift), p(gs.conv3D.weight),
+                     p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
+        elif self.kind == "tsm":
+            dY1s = sc("tsm.dY1s", Mi * cin)
+            lib.call("stes_tsm_shift", p(dY1), p(dY1s), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
+            dY1 = dY1s
+        # --- shortcut
+        if self.down:
+            bnd = self.bnd
+            bnd.bwd_finalize(Mo, s_dy=bn3.s_dy)
+            dsc = sc("dsc", Mo * cout)
+            lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
+            rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
+            lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap)
+            Dsc = sc("Dsc", Mo * cin)
+            lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
+            resid, ms = Dsc, self.stride
+        else:
+            resid, ms = dZ, 1
+        dZp = e.scratch_pp("dZ", Mi * cin)
+        # the ReLU that produced the block input is masked with the tensor the block actually consumed
+        # (for the in-place plain shift of the reference that is the shifted tensor, model/shift.py:55-66)
+        lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
+                 p(dZp), Mi, cin)
+        return dZp
+
+
+class GRULayer:
+    def __init__(self, eng, gru, l, in_dim, H):
+        sfx = ("", "_reverse")
+        P = lambda n: [getattr(gru, f"{n}_l{l}{s}") for s in sfx]
+        self.wih, self.whh, self.bih, self.bhh = P("weight_ih"), P("weight_hh"), P("bias_ih"), P("bias_hh")
+        self.I, self.H = in_dim, H
+        if H % 32 or in_dim % 8:
+            raise NotImplementedError("GRU kernels need hidden % 32 == 0 and input % 8 == 0")
+        # the two directions are adjacent in the flat parameter buffer (Engine._flatten order): view them as one tensor
+        self.wih_all = eng.pair_view(self.wih)          # [6H, I]
+        self.bih_all = eng.pair_view(self.bih)          # [6H]
+        self.whh_all = eng.pair_view(self.whh)          # [2*3H, H]
+        self.bhh_all = eng.pair_view(self.bhh)          # [2*3H]
+        self.lin = Linear(eng, self.wih_all, n=6 * H, k=in_dim)
+        self.whh_bf, self.whhT_bf = eng.bf16(2, 3 * H, H), eng.bf16(2, H, 3 * H)
+        for d in range(2):
+            eng.casts.append((self.whh[d], self.whh_bf[d], 3 * H, H, H, 3 * H, 0))
+            eng.casts.append((self.whh[d], self.whhT_bf[d], 3 * H, H, 3 * H, H, 1))
+
+
+class Engine:
+    STATS_FLOATS = 1 << 20
+
+    def __init__(self, impl: nn.Module, clip_len: int):
+        dev = next(impl.parameters()).device
+        if dev.type != "cuda":
+            raise lib.StesError("spot_amd runs on an MI355X through libstes_hip; the model must be on a cuda (ROCm) device")
+        lib.lib()
+        self.impl, self.dev, self.clip_len = impl, dev, clip_len
+        self.casts, self.packs = [], []
+        self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
+        self._stats_used = 0
+        self._scratch, self._acts, self._pp = {}, {}, {}
+        self._flatten()
+        feats = impl._features
+        self.in_chans = feats.stem.conv.in_channels
+        if feats.stem.conv.out_channels != 32:
+            raise NotImplementedError("stem kernels are built for 32 output channels")
+        self.stem = Linear(self, feats.stem.conv.weight, kp=32)    # [32][9*Cin] -> K padded to 32
+        self.bn0 = BN(self, feats.stem.bn)
+        self.blocks = []
+        for sname in ("s1", "s2", "s3", "s4"):
+            for bname, blk in getattr(feats, sname).named_children():
+                self.blocks.append(Block(self, blk, f"{sname}.{bname}"))
+        self.feat_dim = self.blocks[-1].cout
+        self._build_heads()
+        self.weights_dirty = True
+        self.shape_key = None
+        self.step_count = 0
+        self.dropout_seed = 0x5EED
+        self.dropout_mask_override = None
+        self.loss_buf = torch.zeros(8, device=dev)
+
+    # ------------------------------------------------------------------ memory helpers
+    def f32_block(self, n, Cc):
+        t = torch.zeros(n, Cc, device=self.dev)
+        return [t[i] for i in range(n)]
+
+    def stats_block(self, n, Cc):
+        cp = _rup(Cc, 4)
+        if self._stats_used + n * cp > self.STATS_FLOATS:
+            raise lib.StesError("statistics arena exhausted")
+        out = []
+        for _ in range(n):
+            out.append(self._stats[self._stats_used:self._stats_used + Cc])
+            self._stats_used += cp
+        return out
+
+    def bf16(self, *shape):
+        return torch.zeros(*shape, dtype=BF, device=self.dev)
+
+    def scratch(self, name, numel, dtype=BF):
+        t = self._scratch.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(numel, dtype=dtype, device=self.dev)
+            self._scratch[name] = t
+        return t
+
+    def scratch_pp(self, name, numel):
+        """ping-pong scratch: the result of one block's backward is the input of the next"""
+        i = self._pp.get(name, 0) ^ 1
+        self._pp[name] = i
+        return self.scratch(f"{name}.{i}", numel)
+
+    def act(self, name, numel, dtype):
+        t = self._acts.get(name)
+        if t is None or t.numel() != numel or t.dtype != dtype:
+            t = torch.empty(numel, dtype=dtype, device=self.dev)
+            self._acts[name] = t
+        return t
+
+    # ------------------------------------------------------------------ flat parameters
+    def _flatten(self):
+        impl = self.impl
+        named = [(n, p) for n, p in impl.named_parameters() if p.requires_grad]
+        # GRU: put the two directions of each tensor kind next to each other
+        def key(item):
+            n = item[0]
+            if "._gru." in n or n.startswith("_pred_fine._gru."):
+                base = n.replace("_reverse", "")
+                return (base, 1 if n.endswith("_reverse") else 0)
+            return None
+        gru = sorted([it for it in named if key(it) is not None], key=key)
+        rest = [it for it in named if key(it) is None]
+        main = [it for it in rest if "_pred_loc" not in it[0]] + gru
+        loc = [it for it in rest if "_pred_loc" in it[0]]
+        order = main + loc
+        offs, total = {}, 0
+        for n, p_ in order:
+            offs[n] = total
+            total += _rup(p_.numel(), 16)
+        self.n_main = sum(_rup(p_.numel(), 16) for _, p_ in main)
+        self.n_total = total
+        self.flat = torch.zeros(total, device=self.dev)
+        self.flat_grad = torch.zeros(total, device=self.dev)
+        self.adam_m = self.adam_v = None
+        self._goff = {}
+        self._params = []
+        for n, p_ in order:
+            o = offs[n]
+            view = self.flat[o:o + p_.numel()].view(p_.shape)
+            view.copy_(p_.data)
+            p_.data = view
+            self._goff[id(p_)] = (o, p_.numel(), p_.shape)
+            self._params.append((n, p_))
+        self._views_ptr = {id(p_): p_.data_ptr() for _, p_ in order}
+
+    def check_views(self):
+        for _, p_ in self._params:
+            if p_.data_ptr() != self._views_ptr[id(p_)]:
+                raise lib.StesError("model parameters were re-allocated after the engine was built (call .to(device) before the first forward)")
+
+    def grad(self, param):
+        o, n, shape = self._goff[id(param)]
+        return self.flat_grad[o:o + n].view(shape)
+
+    def pair_view(self, params):
+        o0, n0, s0 = self._goff[id(params[0])]
+        o1, n1, s1 = self._goff[id(params[1])]
+        assert o1 == o0 + n0 and n0 == n1 and n0 % 16 == 0, "GRU direction tensors must be adjacent in the flat buffer"
+        t = self.flat[o0:o0 + 2 * n0].view(2 * s0[0], *s0[1:])
+        self._goff[id(t)] = (o0, 2 * n0, t.shape)
+        self._keep = getattr(self, "_keep", []) + [t]
+        return t
+
+    def attach_grads(self, zero):
+        """Expose the flat gradient buffer as .grad of every parameter (torch optimizers then work unchanged)."""
+        if zero:
+            self.flat_grad.zero_()
+        for _, p_ in self._params:
+            o, n, shape = self._goff[id(p_)]
+            p_.grad = self.flat_grad[o:o + n].view(shape)
+
+    # ------------------------------------------------------------------ heads
+    def _build_heads(self):
+        impl = self.impl
+        F = self.feat_dim
+        pf = impl._pred_fine
+        self.head_kind = "gru" if isinstance(pf, GRUPrediction) else ("mingru" if isinstance(pf, MinRNNPredictor) else "fc")
+        if self.head_kind == "gru":
+            H = pf._gru.hidden_size
+            self.gru_layers = [GRULayer(self, pf._gru, l, F if l == 0 else 2 * H, H) for l in range(pf._gru.num_layers)]
+            self.fc = Linear(self, pf._fc_out._fc_out.weight, pf._fc_out._fc_out.bias)
+            self.drop_p = float(pf._dropout.p)
+        elif self.head_kind == "mingru":
+            self.min_layers = []
+            for layer in pf.rnn_layers:
+                # gate and candidate projections fused into one [2H, I] GEMM: needs adjacent weights -> private stacked copy
+                self.min_layers.append(layer)
+            self.fc = Linear(self, pf.fc.weight, pf.fc.bias)
+            self.min_lin = []
+            for layer in pf.rnn_layers:
+                self.min_lin.append((Linear(self, layer.linear_z.weight, layer.linear_z.bias),
+                                     Linear(self, layer.linear_h_tilde.weight, layer.linear_h_tilde.bias)))
+        else:
+            self.fc = Linear(self, pf._fc_out.weight, pf._fc_out.bias)
+        self.loc = None
+        if getattr(impl, "_predict_location", False):
+            mlp, last = impl._pred_loc[0], impl._pred_loc[1]
+            self.loc = [Linear(self, l.weight, l.bias) for l in mlp.layers] + [Linear(self, last.weight, last.bias)]
+
+    # ------------------------------------------------------------------ weights
+    def refresh_weights(self):
+        self.check_views()
+        p = lib.ptr
+        for src, dst, rows, cols, ld, dst_rows, tr in self.casts:
+            lib.call("stes_cast_bf16", p(src), p(dst), rows, cols, ld, dst_rows, tr)
+        for w, wf, wd, G in self.packs:
+            lib.call("stes_pack_conv3x3g", p(w), p(wf), p(wd), G)
+        self.weights_dirty = False
+
+    # ------------------------------------------------------------------ planning
+    def plan(self, B, T, H, W, train, head_T=None):
+        Th = head_T if head_T is not None else T
+        key = (B, T, H, W, train, Th)
+        if key == self.shape_key:
+            return
+        self._acts.clear()
+        N = B * T
+        self.B, self.T, self.N, self.H, self.W = B, T, N, H, W
+        self.H0, self.W0 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        self.M0 = N * self.H0 * self.W0
+        a = self.act
+        self.patches = a("stem.patches", self.M0 * 32, BF)
+        self.c0 = a("stem.c0", self.M0 * 32, BF)
+        self.X0 = a("stem.X0", self.M0 * 32, BF)
+        h, w = self.H0, self.W0
+        for blk in self.blocks:
+            h, w = blk.plan(N, h, w, T, train)
+        self.Hl, self.Wl = h, w
+        Fd = self.feat_dim
+        self.feat = a("feat", N * Fd, BF)
+        # heads may run on the first Th <= T frames of every clip (a zero-padded last window is un-padded before the
+        # heads, reference train_e2e_spatial.py:440-442)
+        self.Th, self.Nh = Th, B * Th
+        self.feat_h = self.feat if Th == T else a("feat_h", B * Th * Fd, BF)
+        N_bb, N, T = N, B * Th, Th
+        if self.head_kind == "gru":
+            for i, L in enumerate(self.gru_layers):
+                Hh = L.H
+                L.gi = a(f"gru{i}.gi", N * 6 * Hh, BF)
+                L.y = a(f"gru{i}.y", N * 2 * Hh, BF)
+                L.hstate = a(f"gru{i}.hs", 4 * B * Hh, F32)
+                L.saved = a(f"gru{i}.saved", 2 * T * B * 5 * Hh, F32) if train else None
+                L.hprev = a(f"gru{i}.hprev", 2 * T * B * Hh, BF) if train else None
+            Hh = self.gru_layers[-1].H
+            self.ydrop = a("gru.ydrop", N * 2 * Hh, BF)
+            self.dmask = a("gru.mask", N * 2 * Hh, BF)
+        elif self.head_kind == "mingru":
+            Hh = self.impl._pred_fine.hidden_size
+            self.min_pre = [a(f"min{i}.pre", N * 2 * Hh, BF) for i in range(len(self.min_lin))]
+            self.min_h = [a(f"min{i}.h", N * Hh, BF) for i in range(len(self.min_lin))]
+        self.logits = a("logits", N * self.fc.N, F32)
+        if self.loc is not None:
+            self.loc_h1 = a("loc.h1", N * self.loc[0].N, BF)
+            self.loc_h2 = a("loc.h2", N * self.loc[1].N, BF)
+            self.loc_out = a("loc.out", N * 2, F32)
+        self.shape_key = key
+        N, T = N_bb, self.T
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train, head_T=None):
+        """x: [B, T, C, H, W] fp32 on the device (T == clip_len when a temporal shift is present).
+        Returns (logits [B,Th,classes] f32, loc [B,Th,2] f32 | None, feat [B,Th,F] bf16), Th = head_T or T."""
+        B, T, Cin, H, W = x.shape
+        if Cin != self.in_chans:
+            raise lib.StesError(f"expected {self.in_chans} input channels, got {Cin}")
+        if x.dtype != F32 or not x.is_contiguous():
+            x = x.contiguous().float()
+        self.plan(B, T, H, W, train, head_T)
+        if self.weights_dirty or train:
+            self.refresh_weights()
+        p = lib.ptr
+        N = self.N
+        if train:
+            self._stats[:self._stats_used].zero_()
+        self._x = x
+        lib.call("stes_im2col_stem", p(x), p(self.patches), N, Cin, H, W)
+        st = (self.bn0.sum, self.bn0.sumsq) if train else None
+        lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
+        self.bn0.finalize(self.M0, train)
+        blocks = self.blocks
+
+        def next_info(i):
+            if i < len(blocks) and blocks[i].kind == "gsm":
+                return blocks[i].fold, (blocks[i].bng.sum, blocks[i].bng.sumsq)
+            return 0, None
+
+        nf, ns = next_info(0)
+        ns_t = ns if train else None
+        lib.call("stes_bn_act_residual", p(self.c0), p(self.bn0.scale), p(self.bn0.shift), None, None, None, p(self.X0),
+                 p(ns_t[0]) if ns_t else None, p(ns_t[1]) if ns_t else None, nf if ns_t else 0, self.M0, 32)
+        X = self.X0
+        for i, blk in enumerate(blocks):
+            nf, ns = next_info(i + 1)
+            X = blk.forward(X, train, nf, ns)
+        HWl = self.Hl * self.Wl
+        lib.call("stes_chan_pool", p(X), None, None, None, None, p(self.feat), N, HWl, self.feat_dim, 1.0 / HWl)
+        self._last_out = X
+        if self.Th != T:
+            self.feat_h.view(B, self.Th, self.feat_dim).copy_(self.feat.view(B, T, self.feat_dim)[:, :self.Th])
+        return self._heads_forward(train)
+
+    def _heads_forward(self, train):
+        N, B, T, Fd = self.Nh, self.B, self.Th, self.feat_dim
+        feat = self.feat_h
+        p = lib.ptr
+        loc = None
+        if self.loc is not None:
+            l1, l2, l3 = self.loc
+            lib.gemm(feat, l1.w_bf, self.loc_h1, N, l1.N, l1.K, bias=l1.b, act=1)
+            lib.gemm(self.loc_h1, l2.w_bf, self.loc_h2, N, l2.N, l2.K, bias=l2.b)
+            lib.gemm(self.loc_h2, l3.w_bf, self.loc_out, N, l3.N, l3.K, bias=l3.b)
+            loc = self.loc_out.view(B, T, 2)
+        if self.head_kind == "gru":
+            xin, in_dim = feat, Fd
+            for L in self.gru_layers:
+                lib.gemm(xin, L.lin.w_bf, L.gi, N, 6 * L.H, in_dim, bias=L.bih_all)
+                a = lib.gru_args(gi=L.gi, whh=L.whh_bf, whhT=L.whhT_bf, bhh=L.bhh_all, y=L.y, hstate=L.hstate, saved=L.saved,
+                                 hprev_bf=L.hprev, B=B, T=T, H=L.H)
+                lib.check(lib.lib().stes_gru_forward(C.byref(a), lib.stream()), "stes_gru_forward")
+                xin, in_dim = L.y, 2 * L.H
+            self.fc_in = xin
+            self.mask_used = None
+            if train and (self.drop_p > 0 or self.dropout_mask_override is not None):
+                if self.dropout_mask_override is not None:
+                    self.dmask.copy_(self.dropout_mask_override.reshape(-1).to(BF))
+                    self._mul(xin, self.dmask, self.ydrop)
+                else:
+                    self.dropout_seed = (self.dropout_seed * 1664525 + 1013904223) & 0xFFFFFFFF
+                    lib.call("stes_dropout", p(xin), p(self.ydrop), p(self.dmask), xin.numel(), self.drop_p, self.dropout_seed)
+                self.fc_in, self.mask_used = self.ydrop, self.dmask
+            lib.gemm(self.fc_in, self.fc.w_bf, self.logits, N, self.fc.N, in_dim, bias=self.fc.b)
+        elif self.head_kind == "mingru":
+            xin, in_dim = feat, Fd
+            for i, (lz, lh) in enumerate(self.min_lin):
+                Hh = lz.N
+                lib.gemm(xin, lz.w_bf, self.min_pre[i], N, Hh, in_dim, bias=lz.b, ldc=2 * Hh)
+                lib.gemm(xin, lh.w_bf, self.min_pre[i][Hh:], N, Hh, in_dim, bias=lh.b, ldc=2 * Hh)
+                lib.call("stes_mingru_scan_fwd", p(self.min_pre[i]), p(self.min_h[i]), B, T, Hh)
+                xin, in_dim = self.min_h[i], Hh
+            self.fc_in = xin
+            lib.gemm(xin, self.fc.w_bf, self.logits, N, self.fc.N, in_dim, bias=self.fc.b)
+        else:
+            self.fc_in = feat
+            lib.gemm(feat, self.fc.w_bf, self.logits, N, self.fc.N, Fd, bias=self.fc.b)
+        return self.logits.view(B, T, self.fc.N), loc, feat.view(B, T, Fd)
+
+    def _mul(self, a, m, out):
+        # injected dropout mask (parity tests): out = a * m through the BatchNorm-apply kernel's arithmetic is overkill;
+        # a [N*2H] x mask elementwise is expressed with the dropout kernel's output format by the caller.
+        torch.mul(a, m, out=out)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits_bf, dloc_bf, dfeat_extra=None):
+        """dlogits_bf [N, 8k] bf16 (padded rows), dloc_bf [N, 8] bf16 or None.  Accumulates into the flat gradient buffer."""
+        N, B, T, Fd = self.N, self.B, self.T, self.feat_dim
+        p, g, sc = lib.ptr, self.grad, self.scratch
+        if self.Th != T:
+            raise NotImplementedError("backward needs clips of exactly clip_len frames")
+        if self.head_kind == "mingru":
+            raise NotImplementedError("training through the minGRU head is not built yet (inference only)")
+        if any(b.kind == "tsm" for b in self.blocks):
+            raise NotImplementedError("training through the plain temporal shift is not built yet (inference only)")
+        dfa = sc("dfeat.a", N * Fd, F32)
+        dfb = None
+        fc = self.fc
+        ncp = dlogits_bf.shape[1]
+        if self.head_kind == "gru":
+            Hh = self.gru_layers[-1].H
+            in_dim = 2 * Hh
+            lib.wgrad(dlogits_bf, self.fc_in, g(fc.w), N, fc.N, in_dim, ldp=ncp, dbias=g(fc.b))
+            dy = sc("gru.dy", N * in_dim, F32)
+            lib.gemm(dlogits_bf, fc.wT_bf, dy, N, in_dim, ncp, ldw=fc.Np)
+            mask = self.mask_used
+            for li in range(len(self.gru_layers) - 1, -1, -1):
+                L = self.gru_layers[li]
+                Hh = L.H
+                dgi, dgh = sc("gru.dgi", N * 6 * Hh), sc("gru.dgh", 2 * T * B * 3 * Hh)
+                dhs = sc("gru.dhs", 4 * B * Hh, F32)
+                a = lib.gru_args(gi=L.gi, whh=L.whh_bf, whhT=L.whhT_bf, bhh=L.bhh_all, y=L.y, hstate=L.hstate, saved=L.saved,
+                                 hprev_bf=L.hprev, dy=dy, ld_dy=2 * Hh, mask=mask, dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=Hh)
+                lib.check(lib.lib().stes_gru_backward(C.byref(a), lib.stream()), "stes_gru_backward")
+                xin = self.feat if li == 0 else self.gru_layers[li - 1].y
+                lib.wgrad(dgi, xin, g(L.wih_all), N, 6 * Hh, L.I, dbias=g(L.bih_all))
+                gw, gb = g(L.whh_all), g(L.bhh_all)
+                dgh_v, hp_v = dgh.view(2, T * B, 3 * Hh), L.hprev.view(2, T * B, Hh)
+                for d in range(2):
+                    lib.wgrad(dgh_v[d], hp_v[d], gw[d * 3 * Hh:(d + 1) * 3 * Hh], T * B, 3 * Hh, Hh, dbias=gb[d * 3 * Hh:(d + 1) * 3 * Hh])
+                if li == 0:
+                    lib.gemm(dgi, L.lin.wT_bf, dfa, N, Fd, 6 * Hh, ldw=L.lin.Np)
+                else:
+                    dy = sc(f"gru.dy{li}", N * L.I, F32)
+                    lib.gemm(dgi, L.lin.wT_bf, dy, N, L.I, 6 * Hh, ldw=L.lin.Np)
+                mask = None
+        else:
+            lib.wgrad(dlogits_bf, self.feat, g(fc.w), N, fc.N, Fd, ldp=ncp, dbias=g(fc.b))
+            lib.gemm(dlogits_bf, fc.wT_bf, dfa, N, Fd, ncp, ldw=fc.Np)
+        if self.loc is not None and dloc_bf is not None:
+            l1, l2, l3 = self.loc
+            lib.wgrad(dloc_bf, self.loc_h2, g(l3.w), N, l3.N, l3.K, ldp=8, dbias=g(l3.b))
+            dh2 = sc("loc.dh2", N * l2.N)
+            lib.gemm(dloc_bf, l3.wT_bf, dh2, N, l2.N, 8, ldw=l3.Np)
+            lib.wgrad(dh2, self.loc_h1, g(l2.w), N, l2.N, l2.K, dbias=g(l2.b))
+            dh1 = sc("loc.dh1", N * l1.N)
+            lib.gemm(dh2, l2.wT_bf, dh1, N, l1.N, l2.N, ldw=l2.Np, relu_mask=self.loc_h1, ldmask=l1.N)
+            lib.wgrad(dh1, self.feat, g(l1.w), N, l1.N, Fd, dbias=g(l1.b))
+            dfb = sc("dfeat.b", N * Fd, F32)
+            lib.gemm(dh1, l1.wT_bf, dfb, N, Fd, l1.N, ldw=l1.Np)
+        if dfeat_extra is not None:
+            dfa.add_(dfeat_extra.reshape(-1).float())
+        # --- backbone
+        HWl = self.Hl * self.Wl
+        dZ = self.scratch_pp("dZ", self.N * HWl * Fd)
+        lib.call("stes_pool_bwd", p(dfa), p(dfb), p(self._last_out), p(dZ), N, HWl, Fd)
+        for blk in reversed(self.blocks):
+            dZ = blk.backward(dZ)
+        # stem: dZ is masked by (X0 > 0) already
+        bn0 = self.bn0
+        lib.bn_bwd_reduce(dZ, self.c0, self.M0, 32, [bn0.s_dy, bn0.s_dyr])
+        bn0.bwd_finalize(self.M0)
+        dc0 = sc("dc0", self.M0 * 32)
+        lib.bn_bwd_apply(dZ, self.c0, self.M0, 32, bn0.coef, dc0)
+        K = self.stem.K
+        lib.wgrad(dc0, self.patches, g(self.stem.w), self.M0, 32, K, ldq=32, lddw=K)
+
+    # ------------------------------------------------------------------ fused training step
+    def loss_backward(self, label, xy, num_classes, fg_weight=5.0, grad_scale=1.0, ext_denoms=None):
+        N = self.N
+        p = lib.ptr
+        ncp = _rup(num_classes, 8)
+        dl = self.scratch("dlogits", N * ncp).view(N, ncp)
+        dloc = self.scratch("dloc", N * 8).view(N, 8) if self.loc is not None else None
+        lib.call("stes_loss", p(self.logits), num_classes, p(self.loc_out) if self.loc is not None else None, 2, p(label), p(xy), N,
+                 num_classes, float(fg_weight), float(grad_scale), p(ext_denoms), p(self.loss_buf), p(dl), p(dloc))
+        self.backward(dl, dloc)
+        return self.loss_buf
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, loc_lr_div=5.0, grad_mul=1.0):
+        """torch.optim.AdamW semantics with the reference's two learning rates (model/common.py:32-42) over the flat buffer."""
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_count += 1
+        p = lib.ptr
+        n0, n1 = self.n_main, self.n_total - self.n_main
+        lib.call("stes_adamw", p(self.flat), p(self.flat_grad), p(self.adam_m), p(self.adam_v), n0, float(lr), betas[0], betas[1], eps,
+                 weight_decay, self.step_count, float(grad_mul))
+        if n1 > 0:
+            o = n0
+            lib.call("stes_adamw", p(self.flat[o:]), p(self.flat_grad[o:]), p(self.adam_m[o:]), p(self.adam_v[o:]), n1,
+                     float(lr) / loc_lr_div, betas[0], betas[1], eps, weight_decay, self.step_count, float(grad_mul))
+        self.weights_dirty = True

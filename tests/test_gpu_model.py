@@ -1,0 +1,179 @@
+"""Whole hot path on the GPU (through E2EModel -> engine -> C-ABI) against
+ (1) the golden vectors produced by the reference's own modules (tests/golden/full_*.npz, fp32), and
+ (2) the CPU oracle with bf16 storage rounding switched on (same rounding points as the kernels).
+Stated tolerance (north star: "logits and (x,y) within a stated fp32/bf16 tolerance"): the path stores activations
+in bf16 (8 significant bits, 2^-8 relative per rounding) through 14 bottleneck blocks; relative L2 error of the
+features/logits/loc vs the fp32 reference must stay below 1e-2 in eval mode and 3e-2 in training mode (batch
+statistics over 8 frames of a 2x2 map amplify rounding noise: the CPU oracle run in fp32 and with bf16 storage
+rounding differs from ITSELF by 2e-2 on this case); gradients (relative L2 per tensor) below 8e-2 vs fp32 for tensors
+that carry signal."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def build(arch="rny008_gsm", tarch="gru", clip_len=4, seed=3):
+    from oracle import stes_oracle as O
+    from spot_amd.e2e import E2EModel
+    om = O.Impl(7, arch, tarch, clip_len=clip_len, predict_location=True)
+    O.randomize_(om, seed=seed)
+    m = E2EModel(7, arch, tarch, clip_len=clip_len, modality="rgb", device="cuda", predict_location=True, verbose=False)
+    missing = m._model.load_state_dict(om.state_dict(), strict=True)     # state-dict keys are the compatibility surface
+    return om, m
+
+
+def test_state_dict_keys_match_oracle_and_timm_names():
+    om, m = build()
+    ks = set(m.state_dict().keys())
+    assert ks == set(om.state_dict().keys())
+    for k in ("_features.stem.conv.weight", "_features.s1.b1.conv1.gsm.conv3D.weight", "_features.s1.b1.conv1.net.conv.weight",
+              "_features.s3.b4.se.fc1.bias", "_features.s2.b1.downsample.bn.running_var", "_pred_fine._gru.weight_hh_l0_reverse",
+              "_pred_fine._fc_out._fc_out.bias", "_pred_loc.0.layers.1.weight", "_pred_loc.1.bias"):
+        assert k in ks, k
+
+
+def test_eval_forward_vs_reference_golden(golden):
+    z = golden("full_rny008_gsm_gru")
+    om, m = build()
+    x = torch.from_numpy(z["x"])
+    m._model.eval()
+    with torch.no_grad():
+        d = m._model(x.cuda())
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].cpu(), z["eval." + k])
+        print(k, "rel L2 vs reference fp32:", r)
+        assert r < 1e-2, (k, r)
+    cls, scores, loc = m.predict(x)
+    from oracle import stes_oracle as O
+    ocls, oscores, oloc = O.predict(om, x)
+    assert scores.shape == oscores.shape and loc.shape == oloc.shape
+    np.testing.assert_allclose(scores, oscores, atol=2e-2)
+    np.testing.assert_allclose(loc, oloc, atol=2e-2)
+
+
+def test_train_forward_backward_vs_reference_and_oracle(golden):
+    from oracle import stes_oracle as O
+    z = golden("full_rny008_gsm_gru")
+    om, m = build()
+    x, label, xy = torch.from_numpy(z["x"]), torch.from_numpy(z["label"]), torch.from_numpy(z["xy"])
+    impl = m._model
+    impl.train()
+    impl._pred_fine._dropout.p = 0.0
+    impl.engine.drop_p = 0.0
+    d = impl(x.cuda())
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].detach().cpu(), z["train." + k])
+        print(k, "train rel L2 vs reference fp32:", r)
+        assert r < 3e-2, (k, r)
+    # reference-style loss with torch ops on top of the engine outputs, backward through the autograd bridge
+    loss, lc, ll = None, None, None
+    import torch.nn.functional as F
+    w = torch.tensor([1.0] + [5.0] * 6, device="cuda")
+    lab = label.flatten().cuda()
+    lc = F.cross_entropy(d["im_feat"].reshape(-1, 7), lab, weight=w)
+    mask = (lab != 0).float()
+    l1 = F.l1_loss(d["loc_feat"].reshape(-1, 2).sigmoid(), xy.reshape(-1, 2).cuda(), reduction="none").sum(-1)
+    ll = (l1 * mask).sum() / (mask.sum() + 1e-6)
+    np.testing.assert_allclose([lc.item(), ll.item()], z["loss"], rtol=3e-2)
+    (lc + ll).backward()
+    torch.cuda.synchronize()
+    # oracle with the kernels' bf16 storage rounding
+    O.set_storage_rounding(True)
+    try:
+        om.train(); om._pred_fine._dropout.p = 0.0
+        od = om(x)
+        oloss, _, _ = O.stes_loss(od["im_feat"], od["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+        oloss.backward()
+    finally:
+        O.set_storage_rounding(False)
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].detach().cpu(), od[k].detach())
+        print(k, "train rel L2 vs bf16-rounded oracle:", r)
+        assert r < 4e-2, (k, r)
+    # Gradients.  bf16 storage noise flips ReLU masks of near-zero pre-activations, and every flipped element changes
+    # the masked gradient by its full size, so through ~45 ReLU layers the fp32 gradient cannot be matched tightly on a
+    # batch of 8 frames: the CPU oracle run with bf16 storage rounding deviates from its own fp32 run by 20-40 % in
+    # the backbone (2 % in the heads).  That self-deviation is the yardstick: per tensor, the HIP gradient must be as
+    # close to the reference's fp32 gradient as the bf16-rounded oracle is (ratio of the two deviations: median < 1.3,
+    # 95th percentile < 2, max < 3.5 over all tensors), with cosine > 0.75.
+    om32 = O.Impl(7, "rny008_gsm", "gru", clip_len=4, predict_location=True)
+    O.randomize_(om32, seed=3)
+    om32.train(); om32._pred_fine._dropout.p = 0.0
+    o32 = om32(x)
+    l32, _, _ = O.stes_loss(o32["im_feat"], o32["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+    l32.backward()
+    g32 = dict((n, p.grad) for n, p in om32.named_parameters() if p.grad is not None)
+    g16 = dict((n, p.grad) for n, p in om.named_parameters() if p.grad is not None)
+    norms = dict(zip(z["grad_names"].tolist(), z["grad_norms"].tolist()))
+    med = float(np.median(list(norms.values())))
+    report, ratios = [], []
+    for n, p in impl.named_parameters():
+        if p.grad is None:
+            continue
+        ref = torch.from_numpy(z["g." + n]) if "g." + n in z.files else g32[n]     # reference's own fp32 gradient when stored
+        # the stored reference norms pin the oracle's fp32 gradient for every tensor
+        assert abs(float(g32[n].double().norm()) - norms[n]) <= 2e-3 * norms[n] + 1e-7, n
+        ours, yard = rel(p.grad.cpu(), ref), rel(g16[n], ref)
+        a, b = p.grad.cpu().double().flatten(), ref.double().flatten()
+        cosine = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        report.append((ours, yard, cosine, n))
+        if norms[n] > 1e-2 * med and p.numel() >= 64:
+            ratios.append(ours / max(yard, 2e-2))
+            assert cosine > 0.75, (n, cosine)
+    ratios = np.array(ratios)
+    print("ours/yardstick: median %.2f  p95 %.2f  max %.2f over %d tensors" % (np.median(ratios), np.percentile(ratios, 95), ratios.max(), len(ratios)))
+    # one noise realisation per run (the fp32 atomics reorder), so the criterion is on the distribution over the 250+ tensors
+    assert np.median(ratios) < 1.3 and np.percentile(ratios, 95) < 2.0 and ratios.max() < 3.5
+    report.sort(reverse=True)
+    print("largest gradient deviations (ours vs fp32, bf16-oracle vs fp32, cosine, name):")
+    for r in report[:6]:
+        print("   %.3f %.3f %.3f %s" % r)
+    heads = [r for r in report if r[3].startswith("_pred_fine")]
+    assert max(r[0] for r in heads) < 4e-2, heads
+    # running statistics updated like torch BatchNorm
+    for n, b in impl.named_buffers():
+        if "buf." + n in z.files:
+            np.testing.assert_allclose(b.cpu().numpy(), z["buf." + n], rtol=2e-2, atol=2e-3)
+
+
+def test_fused_train_step_matches_reference_step_semantics():
+    """E2EModel.train_step (HIP loss + backward + AdamW) against the oracle's step (torch autograd + torch AdamW with the
+    reference's per-tensor groups and lr/5 for _pred_loc)."""
+    from oracle import stes_oracle as O
+    om, m = build(seed=5)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 3, 64, 64, generator=g)
+    label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+    xy = torch.rand(2, 4, 2, generator=g)
+    m._model._pred_fine._dropout.p = 0.0
+    m._model.engine.drop_p = 0.0
+    om._pred_fine._dropout.p = 0.0
+    opt = O.make_adamw(om, 1e-3)
+    O.set_storage_rounding(True)
+    try:
+        ol = O.train_step(om, opt, x, label, xy, 7)
+    finally:
+        O.set_storage_rounding(False)
+    out = m.train_step(x.cuda(), label.cuda(), xy.cuda(), lr=1e-3)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[:3].cpu().numpy(), ol, rtol=2e-2)
+    # after one AdamW step every weight moved by ~lr*sign(grad): compare the update direction on tensors with signal
+    om0 = O.Impl(7, "rny008_gsm", "gru", clip_len=4, predict_location=True); O.randomize_(om0, seed=5)
+    p0 = dict(om0.named_parameters())
+    agree, total = 0, 0
+    for n, p in m._model.named_parameters():
+        du_ours = (p.detach().cpu() - p0[n].detach()).flatten()
+        du_ref = (dict(om.named_parameters())[n].detach() - p0[n].detach()).flatten()
+        sel = du_ref.abs() > 5e-4                     # well-determined updates (|m/sqrt(v)| ~ 1 at step 1)
+        agree += int((torch.sign(du_ours[sel]) == torch.sign(du_ref[sel])).sum()); total += int(sel.sum())
+    print("AdamW update sign agreement:", agree / max(total, 1), total)
+    # the first AdamW update is lr*sign(g) elementwise; with the gradient noise quantified above (cosine ~0.92 in the
+    # deepest layers) ~5 % of the signs differ between two bf16 runs
+    assert agree / max(total, 1) > 0.9
