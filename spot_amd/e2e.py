@@ -247,7 +247,7 @@ class E2EModel(BaseRGBModel):
 
     # ------------------------------------------------------------------ fused training step (HIP loss + backward + AdamW)
     def train_step(self, frame, label, xy, lr, fg_weight=5.0, grad_scale=1.0, ext_denoms=None, optimizer_step=True,
-                   after_backward=None, grad_mul=1.0):
+                   after_backward=None, grad_mul=1.0, on_ready=None):
         """One optimisation step entirely on the device.  frame [B,T,C,H,W] f32, label [B,T] int64, xy [B,T,2] f32.
         Returns the device tensor {sum, cls, loc, sum of class weights, number of event frames} (no host sync)."""
         m = self._model
@@ -258,7 +258,7 @@ class E2EModel(BaseRGBModel):
         eng.forward(frame, train=True)
         eng.attach_grads(zero=True)
         out = eng.loss_backward(label.reshape(-1), xy.reshape(-1, 2) if xy is not None else None, self._num_classes,
-                                fg_weight=fg_weight, grad_scale=grad_scale, ext_denoms=ext_denoms)
+                                fg_weight=fg_weight, grad_scale=grad_scale, ext_denoms=ext_denoms, on_ready=on_ready)
         if after_backward is not None:
             after_backward(eng)
         if optimizer_step:

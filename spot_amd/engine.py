@@ -380,6 +380,13 @@ class Engine:
             total += _rup(p_.numel(), 16)
         self.n_main = sum(_rup(p_.numel(), 16) for _, p_ in main)
         self.n_total = total
+        # gradient buckets for the data-parallel all-reduce, in the order the backward pass completes them: heads
+        # (end of the buffer) first, then s4, s3, and finally s2 + s1 + stem
+        def first(prefix):
+            return min(offs[n] for n, _ in order if n.startswith(prefix))
+        heads_lo = min(offs[n] for n, _ in order if not n.startswith("_features."))
+        self.buckets = {"heads": (heads_lo, total), "s4": (first("_features.s4."), heads_lo),
+                        "s3": (first("_features.s3."), first("_features.s4.")), "rest": (0, first("_features.s3."))}
         self.flat = torch.zeros(total, device=self.dev)
         self.flat_grad = torch.zeros(total, device=self.dev)
         self.adam_m = self.adam_v = None
@@ -601,8 +608,9 @@ class Engine:
         torch.mul(a, m, out=out)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dlogits_bf, dloc_bf, dfeat_extra=None):
-        """dlogits_bf [N, 8k] bf16 (padded rows), dloc_bf [N, 8] bf16 or None.  Accumulates into the flat gradient buffer."""
+    def backward(self, dlogits_bf, dloc_bf, dfeat_extra=None, on_ready=None):
+        """dlogits_bf [N, 8k] bf16 (padded rows), dloc_bf [N, 8] bf16 or None.  Accumulates into the flat gradient buffer.
+        on_ready(lo, hi) is called as soon as flat_grad[lo:hi] is final (gradient all-reduce overlapped with backward)."""
         N, B, T, Fd = self.N, self.B, self.T, self.feat_dim
         p, g, sc = lib.ptr, self.grad, self.scratch
         if self.Th != T:
@@ -662,8 +670,12 @@ class Engine:
         HWl = self.Hl * self.Wl
         dZ = self.scratch_pp("dZ", self.N * HWl * Fd)
         lib.call("stes_pool_bwd", p(dfa), p(dfb), p(self._last_out), p(dZ), N, HWl, Fd)
+        if on_ready:
+            on_ready(*self.buckets["heads"])
         for blk in reversed(self.blocks):
             dZ = blk.backward(dZ)
+            if on_ready and blk.name in ("s4.b1", "s3.b1"):
+                on_ready(*self.buckets[blk.name[:2]])
         # stem: dZ is masked by (X0 > 0) already
         bn0 = self.bn0
         lib.bn_bwd_reduce(dZ, self.c0, self.M0, 32, [bn0.s_dy, bn0.s_dyr])
@@ -672,9 +684,11 @@ class Engine:
         lib.bn_bwd_apply(dZ, self.c0, self.M0, 32, bn0.coef, dc0)
         K = self.stem.K
         lib.wgrad(dc0, self.patches, g(self.stem.w), self.M0, 32, K, ldq=32, lddw=K)
+        if on_ready:
+            on_ready(*self.buckets["rest"])
 
     # ------------------------------------------------------------------ fused training step
-    def loss_backward(self, label, xy, num_classes, fg_weight=5.0, grad_scale=1.0, ext_denoms=None):
+    def loss_backward(self, label, xy, num_classes, fg_weight=5.0, grad_scale=1.0, ext_denoms=None, on_ready=None):
         N = self.N
         p = lib.ptr
         ncp = _rup(num_classes, 8)
@@ -682,7 +696,7 @@ class Engine:
         dloc = self.scratch("dloc", N * 8).view(N, 8) if self.loc is not None else None
         lib.call("stes_loss", p(self.logits), num_classes, p(self.loc_out) if self.loc is not None else None, 2, p(label), p(xy), N,
                  num_classes, float(fg_weight), float(grad_scale), p(ext_denoms), p(self.loss_buf), p(dl), p(dloc))
-        self.backward(dl, dloc)
+        self.backward(dl, dloc, on_ready=on_ready)
         return self.loss_buf
 
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, loc_lr_div=5.0, grad_mul=1.0):
