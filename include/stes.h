@@ -50,6 +50,7 @@ typedef struct {
     void* C; int64_t ldc; int32_t c_f32;      /* output bf16 (0) or f32 (1) */
     float* col_sum; float* col_sumsq;
     const uint16_t* relu_mask; int64_t ldmask; /* optional: C[m,n] = 0 where relu_mask[m,n] <= 0 (ReLU backward) */
+    uint16_t* C0; int64_t ldc0; int32_t n_split; /* optional: columns [0,n_split) go to the compact bf16 tensor C0 instead */
     int64_t M; int32_t N; int32_t K;
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
@@ -66,6 +67,7 @@ typedef struct {
     int32_t map_stride, Ho, Wo, Hi, Wi;
     float* dW; int64_t lddw;
     float* dbias;
+    int32_t perm_fold;    /* > 0: output column c < perm_fold is stored at column dest(c) (gated-shift interleave) */
     int64_t M; int32_t N1; int32_t N2;
 } stes_wgrad_args;
 int stes_wgrad(const stes_wgrad_args* a, void* stream);
@@ -83,11 +85,12 @@ int stes_bn_finalize(const float* sum, const float* sumsq, double count, const f
                      float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
 
 /* out = relu(scale*c + shift + r), r = res_scale*res + res_shift | res | 0; optional sum / sum of
- * squares of out's first stat_c channels (the next block's gated-shift BatchNorm3d input).
+ * squares of out's first stat_c channels (the next block's gated-shift BatchNorm3d input) and a compact
+ * copy slice_out [M][stat_c] of those channels.
  * Replaces: conv3.bn + shortcut add + act3 of the timm Bottleneck, and stem bn + ReLU.   */
 int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
                          const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
-                         float* stat_sumsq, int stat_c, int64_t M, int C, void* stream);
+                         float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, void* stream);
 
 /* out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1), act = relu(scale*c+shift)
  * when scale is given.  Squeeze of timm SEModule, its backward, and the head's global pool.   */
@@ -150,31 +153,35 @@ int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, const float* i
 int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, int W, void* stream);
 
 /* ---------------------------------------------------- temporal shift ----
- * Gated Shift Module, reference model/shift.py:83-161 (_GSM.forward :103-130, GatedShift.forward
- * :157-161).  X is the block input [B*T*H*W][ldx] NHWC bf16; the module acts on channels [0,fold).
- *   stes_gsm_gate : gate[m,2] = tanh(conv3D(relu(scale*x+shift)))   (scale/shift = BatchNorm3d, from
- *                   stes_bn_finalize; conv3D weight [2][fold/2][3][3][3], bias [2], fp32)
- *   stes_gsm_shift: G[m, dest(c)] = y[t+1|t-1] + (x - y), y = gate*x; G is compact [M][fold]
- * and the backward pieces (dG is read with row stride ldg, destination-channel order):
- *   stes_gsm_bwd_gate    : dpre[m,2], gradient at the conv3D output (before tanh')
- *   stes_gsm_bwd_wgrad   : dw [2][fold/2][27], db [2]  += (atomics)
- *   stes_gsm_bwd_bnreduce: BatchNorm3d backward sums, s_dy += sum d, s_dyx += sum d*x
- *   stes_gsm_bwd_dx      : dXf[m][fold] = shift path + gate path + BatchNorm3d path         */
-typedef struct { int32_t B, T, H, W, ldx, fold; } stes_gsm_geom;
-int stes_gsm_gate(const uint16_t* X, const float* scale, const float* shift, const float* w3d, const float* b3d,
+ * Gated Shift Module, reference model/shift.py:83-161 (_GSM.forward :103-130, GatedShift.forward :157-161).
+ * Xc is the COMPACT copy [B*T*H*W][fold] (NHWC bf16) of the first `fold` channels of the block input.  All tensors keep
+ * the SOURCE channel order; the reference's within-group interleave dest(c) (:124-128) is applied by the consumer
+ * (stes_cast_bf16 / stes_wgrad `perm_fold`).  fold must be 8 or a multiple of 16 (regnety_008: 8,16,32,80,192).
+ *   stes_gsm_prep  : conv3D weight [2][fold/2][27] -> [2][27][fold/2] (layout of the gate kernel's scalar loads)
+ *   stes_gsm_gate  : gate[m,2] = tanh(conv3D(relu(scale*x+shift)))    (scale/shift = BatchNorm3d via stes_bn_finalize)
+ *   stes_gsm_shift : G[m,c] = y[t+1|t-1] + (x - y), y = gate*x
+ *   stes_gsm_bwd_gate : dpre[m,2], gradient at the conv3D output (tanh' applied), from dG (source order)
+ *   stes_gsm_bwd_wgrad: dw [2][fold/2][27], db [2]  += (atomics)
+ *   stes_gsm_dxbn     : gradient at the BatchNorm3d output, ReLU mask applied, bf16 [M][fold]
+ *                       (then stes_bn_bwd_reduce / _finalize with D = dxbn, raw1 = Xc)
+ *   stes_gsm_bwd_dx   : dXf = dG + gate*(dG[t-+1] - dG) + alpha*dxbn + beta*x + delta                      */
+typedef struct { int32_t B, T, H, W, fold; } stes_gsm_geom;
+int stes_gsm_prep(const float* w3d, float* wt, int fold, void* stream);
+int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const float* wt, const float* b3d,
                   float* gate, const stes_gsm_geom* g, void* stream);
-int stes_gsm_shift(const uint16_t* X, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream);
-int stes_gsm_bwd_gate(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, float* dpre,
+int stes_gsm_shift(const uint16_t* Xc, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_gate(const uint16_t* dG, const uint16_t* Xc, const float* gate, float* dpre,
                       const stes_gsm_geom* g, void* stream);
-int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* X, const float* scale, const float* shift, float* dw,
+int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, float* dw,
                        float* db, const stes_gsm_geom* g, void* stream);
-int stes_gsm_bwd_bnreduce(const float* dpre, const uint16_t* X, const float* scale, const float* shift, const float* w3d,
-                          float* s_dy, float* s_dyx, const stes_gsm_geom* g, void* stream);
-int stes_gsm_bwd_dx(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, const float* dpre,
-                    const float* scale, const float* shift, const float* w3d, const float* alpha, const float* beta,
-                    const float* delta, uint16_t* dXf, const stes_gsm_geom* g, void* stream);
-/* per-column sum / sum of squares of X[:, :ncols] (atomics) */
-int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, void* stream);
+int stes_gsm_dxbn(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d,
+                  uint16_t* dxbn, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_dx(const uint16_t* dG, const uint16_t* Xc, const float* gate, const uint16_t* dxbn,
+                    const float* alpha, const float* beta, const float* delta, uint16_t* dXf, const stes_gsm_geom* g,
+                    void* stream);
+/* per-column sum / sum of squares of X[:, :ncols] (atomics) and/or a compact copy [M][ncols] of that slice */
+int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, uint16_t* copy,
+                   void* stream);
 /* TemporalShift.shift, reference model/shift.py:37-52 (out of place; backward = adjoint shift). */
 int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C, int B, int T, int H, int W, int backward, void* stream);
 
@@ -208,8 +215,10 @@ int stes_loss(const float* logits, int64_t ldl, const float* loc, int64_t ldloc,
 /* torch.optim.AdamW update over a flat fp32 range (model/common.py:40, step() :61-75). */
 int stes_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, float grad_mul, void* stream);
-/* fp32 [rows][cols] -> bf16 [dst_rows][ld], optionally transposed, zero padded. */
-int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, void* stream);
+/* fp32 [rows][cols] -> bf16 [dst_rows][ld], optionally transposed, zero padded; perm_fold > 0 reads the first
+ * perm_fold source columns through the gated-shift channel interleave (see the temporal shift section). */
+int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, int perm_fold,
+                   void* stream);
 
 #ifdef __cplusplus
 }

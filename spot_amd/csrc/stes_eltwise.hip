@@ -66,7 +66,7 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, double 
 __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
     const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
-    bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, long M, int C) {
+    bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, bf16* __restrict__ slice_out, long M, int C) {
     extern __shared__ float lds[];     // [2][stat_c]
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -101,11 +101,14 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
         for (int i = 0; i < 8; ++i) { o[i] = (bf16)fmaxf(v[i], 0.f); v[i] = (float)o[i]; }
         *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
         if (c0 < stat_c) {
+            if (slice_out) *reinterpret_cast<bf16x8*>(slice_out + m * stat_c + c0) = o;
+            if (stat_sum) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
+                for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
+            }
         }
     }
-    if (stat_c > 0) {
+    if (stat_c > 0 && stat_sum) {
         __syncthreads();
         if (c0 < stat_c) {
 #pragma unroll
@@ -424,13 +427,14 @@ extern "C" int stes_bn_finalize(const float* sum, const float* sumsq, double cou
 
 extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
                                     const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
-                                    float* stat_sumsq, int stat_c, int64_t M, int C, void* stream) {
+                                    float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, void* stream) {
     STES_CHECK(c && scale && shift && out && M > 0, STES_ERR_ARG, "stes_bn_act_residual: null pointer");
     STES_CHECK(C % 8 == 0 && stat_c % 8 == 0 && stat_c <= C, STES_ERR_ARG, "stes_bn_act_residual: C and stat_c must be multiples of 8");
-    STES_CHECK(stat_c == 0 || (stat_sum && stat_sumsq), STES_ERR_ARG, "stes_bn_act_residual: stats pointers");
+    STES_CHECK((stat_sum == nullptr) == (stat_sumsq == nullptr), STES_ERR_ARG, "stes_bn_act_residual: stats pointers");
+    STES_CHECK(stat_c == 0 || stat_sum || slice_out, STES_ERR_ARG, "stes_bn_act_residual: stat_c without an output");
     const int grid = flat_grid(M, C / 8);
     hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
-                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (long)M, C);
+                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
                         for (int r = 0; r < 4; ++r) if (nb + r < N) c[r] = v[r];
                     }
                 } else {
-                    bf16* c = (bf16*)p.C + m * p.ldc + nb;
+                    bf16* c = (nb < p.n_split) ? (bf16*)p.C0 + m * p.ldc0 + nb : (bf16*)p.C + m * p.ldc + nb;
                     bf16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { o[r] = (bf16)v[r]; v[r] = (float)o[r]; }
@@ -251,6 +251,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
 constexpr int WK = 32;                       // rows (reduction) per step
 __device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+}
+// within-group channel interleave of the gated shift (reference model/shift.py:124-128)
+__device__ __forceinline__ int gsm_dest(int c, int fold) {
+    const int half = fold >> 1, quarter = fold >> 2;
+    const int g = c / half, rem = c - g * half;
+    const int i = rem / quarter, j = rem - i * quarter;
+    return g * half + 2 * j + i;
 }
 
 template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
@@ -392,10 +399,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
 #pragma unroll
         for (int j = 0; j < FI; ++j) {
             const int n2 = n2_0 + w2 * (T / 2) + j * 16 + fr;
+            const int n2d = n2 < p.perm_fold ? gsm_dest(n2, p.perm_fold) : n2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + w1 * (T / 2) + i * 16 + fq * 4 + r;
-                if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.dW + (long)n1 * p.lddw + n2, acc[i][j][r]);
+                if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.dW + (long)n1 * p.lddw + n2d, acc[i][j][r]);
             }
         }
     if (do_bias) {
@@ -418,6 +426,7 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     STES_CHECK(a->map_stride <= 1 || (a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0), STES_ERR_ARG, "stes_gemm: row map dims");
     STES_CHECK((a->col_sum == nullptr) == (a->col_sumsq == nullptr), STES_ERR_ARG, "stes_gemm: stats pointers");
     STES_CHECK(!(a->col_sum && a->c_f32), STES_ERR_ARG, "stes_gemm: stats need bf16 output");
+    STES_CHECK(a->n_split == 0 || (a->C0 && !a->c_f32 && a->n_split % 4 == 0 && a->ldc0 % 4 == 0 && a->ldc0 >= a->n_split), STES_ERR_ARG, "stes_gemm: split output");
     const int m_tiles = stes_div_up(a->M, BM);
     const bool wide = a->N > 64;
     const int bn = wide ? 128 : 64;

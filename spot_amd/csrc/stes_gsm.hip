@@ -1,19 +1,23 @@
-// Gated Shift Module (reference model/shift.py:83-161) and plain temporal shift (:21-78) on
-// NHWC bf16 activations.  Rows are m = ((clip*T + t)*H + h)*W + w; the module acts on the first
-// `fold` channels of each row and never crosses a clip boundary.
+// Gated Shift Module (reference model/shift.py:83-161) and plain temporal shift (:21-78) on bf16 activations.
 //
-//   gate  : g[m, grp] = tanh(conv3d_{3x3x3, groups=2}(relu(bn3d(x)))[m, grp])          (fp32)
-//   shift : out[m, dest(c)] = y[t+1 | t-1] + (x - y),  y = g*x  (group 0 pulls t+1, group 1 t-1,
-//           zero at the clip edge), dest = within-group interleave of the reference's view/permute
-//   backward: gate-gradient, conv3d weight/bias gradient, BatchNorm3d reductions, input gradient.
-// The fold slice is a small fraction of the tensor (<= 1/4 of the channels); all kernels are
-// gather-style and lean on L2 for the 27-point neighbourhood.
+// The module acts on the first `fold` channels of the block input.  Its producer writes that slice a second time as a
+// COMPACT tensor Xc [M][fold] (rows m = ((clip*T + t)*H + h)*W + w), so every kernel here streams unit-stride rows.
+// Channel order everywhere is the SOURCE order; the reference's within-group interleave (view/permute at
+// model/shift.py:124-128) is folded into the column order of the 1x1 convolution that consumes the result.
+//
+//   gate   : g[m,grp] = tanh(conv3d_{3x3x3,groups=2}(relu(bn3d(x)))) -- one workgroup per (clip, frame, row tile, group):
+//            BN+ReLU applied once while the 3-frame halo tile is staged into LDS, taps unrolled from LDS with the conv
+//            weights coming through scalar loads (they are wave-uniform);
+//   shift  : G[m,c] = y[t+1 | t-1] + (x - y), y = g*x  (group 0 pulls t+1, group 1 pulls t-1, zero at the clip edge);
+//   backward: gate-gradient (elementwise), conv3d weight gradient (reduction over positions on MFMA, operands
+//            transposed through LDS with ds_read_b64_tr_b16), gradient at the BatchNorm3d output (27-tap gather of the
+//            gate gradient staged in LDS, weights scalar), final input gradient (elementwise).
 #include "stes_common.h"
 
 namespace {
 
 struct Geom {
-    int B, T, H, W, ldx, fold;
+    int B, T, H, W, fold;
     long M;
 };
 
@@ -24,229 +28,377 @@ __device__ __forceinline__ int dest_of(int c, int fold) {
     return g * half + 2 * j + i;
 }
 
-struct Pos { int b, t, h, w; };
-__device__ __forceinline__ Pos decode(long m, const Geom& gm) {
-    Pos p;
-    p.w = (int)(m % gm.W); long r = m / gm.W;
-    p.h = (int)(r % gm.H); r /= gm.H;
-    p.t = (int)(r % gm.T); p.b = (int)(r / gm.T);
-    return p;
+// ------------------------------------------------------------------ weight prep: [2][half][27] -> [2][27][half]
+__global__ void gsm_prep_kernel(const float* __restrict__ w, float* __restrict__ wt, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * half * 27) return;
+    const int tap = i % 27, c = (i / 27) % half, g = i / (27 * half);
+    wt[((long)g * 27 + tap) * half + c] = w[i];
 }
 
 // ------------------------------------------------------------------ gate
-// one thread per (row, group); weights [2][half][27] fp32 in LDS
-__global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ X, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ w3d,
-                                                       const float* __restrict__ b3d, float* __restrict__ gate, Geom gm) {
-    extern __shared__ float lds[];     // w[half*27] + scale[half] + shift[half]
-    const int half = gm.fold >> 1, grp = blockIdx.y;
-    float* sw = lds; float* ss = lds + half * 27; float* sb = ss + half;
-    for (int i = threadIdx.x; i < half * 27; i += blockDim.x) sw[i] = w3d[(long)grp * half * 27 + i];
-    for (int i = threadIdx.x; i < half; i += blockDim.x) { ss[i] = scale[grp * half + i]; sb[i] = shift[grp * half + i]; }
+// V = channels per vector (4 when half == 4, else 8).  grid (row tiles, T, B*2)
+template <int V>
+__global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ Xc, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ wt,
+                                                       const float* __restrict__ b3d, float* __restrict__ gate, Geom gm, int TH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
+    const int fold = gm.fold, half = fold >> 1;
+    const int grp = blockIdx.z & 1, b = blockIdx.z >> 1, t = blockIdx.y, h0 = blockIdx.x * TH;
+    const int W = gm.W, H = gm.H, W2 = W + 2, rows = TH + 2;
+    bf16* tile = (bf16*)smem;                              // [3][rows][W2][half]
+    const int nchunk = half / V;
+    const long plane = (long)H * W;
+    const float* sc = scale + grp * half;
+    const float* sh = shift + grp * half;
+    // stage: zero everything that is outside the clip / image, BN + ReLU the rest
+    const int items = 3 * rows * W2 * nchunk;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int ch = i % nchunk; int r = i / nchunk;
+        const int wp = r % W2; r /= W2;
+        const int hr = r % rows, kt = r / rows;
+        const int tt = t + kt - 1, hh = h0 + hr - 1, ww = wp - 1;
+        vecb v;
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = (bf16)0.f;
+        if (tt >= 0 && tt < gm.T && hh >= 0 && hh < H && ww >= 0 && ww < W) {
+            const long m = ((long)(b * gm.T + tt)) * plane + (long)hh * W + ww;
+            const vecb x = *reinterpret_cast<const vecb*>(Xc + m * fold + grp * half + ch * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = (bf16)fmaxf((float)x[k] * sc[ch * V + k] + sh[ch * V + k], 0.f);
+        }
+        *reinterpret_cast<vecb*>(tile + (((long)kt * rows + hr) * W2 + wp) * half + ch * V) = v;
+    }
     __syncthreads();
     const float bias = b3d[grp];
-    const long plane = (long)gm.H * gm.W;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < gm.M; m += (long)gridDim.x * blockDim.x) {
-        const Pos p = decode(m, gm);
+    const float* wg = wt + (long)grp * 27 * half;          // [27][half], wave-uniform -> scalar loads
+    const int nout = TH * W;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int hr = o / W, ww = o - hr * W;
+        const int hh = h0 + hr;
+        if (hh >= H) continue;
         float acc = bias;
-        for (int kt = 0; kt < 3; ++kt) {
-            const int t = p.t + kt - 1;
-            if (t < 0 || t >= gm.T) continue;
-            for (int kh = 0; kh < 3; ++kh) {
-                const int h = p.h + kh - 1;
-                if (h < 0 || h >= gm.H) continue;
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int w = p.w + kw - 1;
-                    if (w < 0 || w >= gm.W) continue;
-                    const bf16* xp = X + (m + (long)(kt - 1) * plane + (long)(kh - 1) * gm.W + (kw - 1)) * gm.ldx + grp * half;
-                    const int tap = (kt * 3 + kh) * 3 + kw;
-                    for (int c = 0; c < half; c += 4) {
-                        const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp + c);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc += sw[(c + i) * 27 + tap] * fmaxf((float)v[i] * ss[c + i] + sb[c + i], 0.f);
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bf16* p = tile + (((long)kt * rows + hr + kh) * W2 + ww + kw) * half;
+                    const float* wv = wg + ((kt * 3 + kh) * 3 + kw) * half;
+                    for (int c = 0; c < half; c += V) {
+                        const vecb x = *reinterpret_cast<const vecb*>(p + c);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) acc += wv[c + k] * (float)x[k];
                     }
                 }
-            }
-        }
+        const long m = ((long)(b * gm.T + t)) * plane + (long)hh * W + ww;
         gate[m * 2 + grp] = tanhf(acc);
     }
 }
 
-// ------------------------------------------------------------------ shift (forward)
-// thread per (row, destination channel)
-__global__ __launch_bounds__(256) void gsm_shift_kernel(const bf16* __restrict__ X, const float* __restrict__ gate,
+// ------------------------------------------------------------------ shift (forward), thread per (row, V-channel chunk)
+template <int V>
+__global__ __launch_bounds__(256) void gsm_shift_kernel(const bf16* __restrict__ Xc, const float* __restrict__ gate,
                                                         bf16* __restrict__ G, Geom gm) {
-    const int fold = gm.fold, half = fold >> 1, quarter = fold >> 2;
+    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
+    const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
-    const long total = gm.M * fold;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / fold; const int d = (int)(i - m * fold);
-        const int g = d / half, rem = d - g * half;
-        const int c = g * half + (rem & 1) * quarter + (rem >> 1);      // source channel of destination d
+    const long total = gm.M * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nch; const int c0 = (int)(i - m * nch) * V;
+        const int g = c0 >= half;
         const int t = (int)((m / plane) % gm.T);
-        const float x = (float)X[m * gm.ldx + c];
-        const float y = gate[m * 2 + g] * x;
-        const float r = x - y;
-        float ys = 0.f;
+        const vecb x = *reinterpret_cast<const vecb*>(Xc + m * fold + c0);
+        const float gt = gate[m * 2 + g];
         const int tn = g == 0 ? t + 1 : t - 1;
-        if (tn >= 0 && tn < gm.T) {
-            const long mn = g == 0 ? m + plane : m - plane;
-            ys = gate[mn * 2 + g] * (float)X[mn * gm.ldx + c];
+        const bool has = tn >= 0 && tn < gm.T;
+        const long mn = g == 0 ? m + plane : m - plane;
+        vecb xn;
+        float gn = 0.f;
+        if (has) { xn = *reinterpret_cast<const vecb*>(Xc + mn * fold + c0); gn = gate[mn * 2 + g]; }
+        vecb o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xv = (float)x[k];
+            const float y = gt * xv;
+            const float r = xv - y;
+            const float ys = has ? gn * (float)xn[k] : 0.f;
+            o[k] = (bf16)(ys + r);
         }
-        G[m * fold + d] = (bf16)(ys + r);
+        *reinterpret_cast<vecb*>(G + m * fold + c0) = o;
     }
 }
 
 // ------------------------------------------------------------------ backward: gate pre-activation gradient
-// dpre[m,g] = (1 - gate^2) * sum_{c in g} x[m,c] * (dG[m -+ plane, dest(c)] - dG[m, dest(c)])
-__global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restrict__ dG, long ldg, const bf16* __restrict__ X,
+// dpre[m,g] = (1 - gate^2) * sum_{c in g} x[m,c] * (dG[m -+ plane, c] - dG[m, c]);  thread per (m, g)
+template <int V>
+__global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restrict__ dG, const bf16* __restrict__ Xc,
                                                            const float* __restrict__ gate, float* __restrict__ dpre, Geom gm) {
+    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
     const int fold = gm.fold, half = fold >> 1;
     const long plane = (long)gm.H * gm.W;
     const long total = gm.M * 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long m = i >> 1; const int g = (int)(i & 1);
         const int t = (int)((m / plane) % gm.T);
         const int tp = g == 0 ? t - 1 : t + 1;                 // frame whose output used y[t]
         const bool has = tp >= 0 && tp < gm.T;
         const long mp = g == 0 ? m - plane : m + plane;
+        const long base = m * fold + g * half, basep = mp * fold + g * half;
         float acc = 0.f;
-        for (int cc = 0; cc < half; ++cc) {
-            const int c = g * half + cc, d = dest_of(c, fold);
-            float dy = -(float)dG[m * ldg + d];
-            if (has) dy += (float)dG[mp * ldg + d];
-            acc += dy * (float)X[m * gm.ldx + c];
+        for (int c = 0; c < half; c += V) {
+            const vecb x = *reinterpret_cast<const vecb*>(Xc + base + c);
+            const vecb d0 = *reinterpret_cast<const vecb*>(dG + base + c);
+            if (has) {
+                const vecb d1 = *reinterpret_cast<const vecb*>(dG + basep + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc += ((float)d1[k] - (float)d0[k]) * (float)x[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc -= (float)d0[k] * (float)x[k];
+            }
         }
         const float gt = gate[i];
         dpre[i] = acc * (1.f - gt * gt);
     }
 }
 
-// ------------------------------------------------------------------ backward: conv3d weight / bias gradient
-// outputs o = tap*fold + c; each block reduces a chunk of rows
-__global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restrict__ dpre, const bf16* __restrict__ X,
+// ------------------------------------------------------------------ backward: conv3d weight / bias gradient on MFMA
+// dw[grp][c][tap] += sum_p xbr[p, c] * dpre[p - off(tap), grp]: reduction over positions p.
+// Per 32 positions: A = Dm^T (rows = taps, 27 -> 32), B = Xb (cols = channels), both read transposed from LDS.
+// grid (workgroups, 2 groups); each workgroup walks 32-position chunks and keeps its accumulators in registers.
+__device__ __forceinline__ int rho32(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+template <int NCT>     // channel tiles of 16 per group (half <= 16*NCT)
+__global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ dw, float* __restrict__ db, Geom gm, int rows_per_block) {
+                                                            float* __restrict__ dw, float* __restrict__ db, Geom gm, long n_chunks) {
+    constexpr int CP = NCT * 16;                                   // padded channels
+    constexpr int LDX = CP + 16;
+    __shared__ __attribute__((aligned(16))) bf16 Dm[4][32 * 48];   // per wave: [32 pos (rho)][32 taps + 16 pad]
+    __shared__ __attribute__((aligned(16))) bf16 Xb[4][32 * LDX];  // per wave: [32 pos (rho)][CP + 16 pad]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int grp = blockIdx.y;
     const int fold = gm.fold, half = fold >> 1;
-    const long plane = (long)gm.H * gm.W;
-    const long m0 = (long)blockIdx.x * rows_per_block;
-    const long m1 = m0 + rows_per_block < gm.M ? m0 + rows_per_block : gm.M;
-    for (int o = threadIdx.x; o < 27 * fold; o += blockDim.x) {
-        const int tap = o / fold, c = o - tap * fold;
-        const int g = c / half;
-        const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const float s = scale[c], b = shift[c];
-        float acc = 0.f;
-        for (long m = m0; m < m1; ++m) {
-            const Pos p = decode(m, gm);
-            const int t = p.t + kt - 1, h = p.h + kh - 1, w = p.w + kw - 1;
-            if (t < 0 || t >= gm.T || h < 0 || h >= gm.H || w < 0 || w >= gm.W) continue;
-            const long ms = m + (long)(kt - 1) * plane + (long)(kh - 1) * gm.W + (kw - 1);
-            acc += dpre[m * 2 + g] * fmaxf((float)X[ms * gm.ldx + c] * s + b, 0.f);
-        }
-        atomicAdd(dw + (long)c * 27 + tap, acc);
-    }
-    if (threadIdx.x < 2) {
-        float acc = 0.f;
-        for (long m = m0; m < m1; ++m) acc += dpre[m * 2 + threadIdx.x];
-        atomicAdd(db + threadIdx.x, acc);
-    }
-}
-
-// gradient reaching the BatchNorm3d output (after the ReLU mask) at (m, c)
-__device__ __forceinline__ float dxbn_at(long m, int c, int g, const Pos& p, const float* __restrict__ dpre, const float* sw,
-                                         float xbn, const Geom& gm, long plane) {
-    if (!(xbn > 0.f)) return 0.f;
-    float acc = 0.f;
+    const int H = gm.H, W = gm.W, T = gm.T;
+    const long plane = (long)H * W;
+    f32x4 acc[2][NCT];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-        const int t = p.t - (kt - 1);
-        if (t < 0 || t >= gm.T) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int h = p.h - (kh - 1);
-            if (h < 0 || h >= gm.H) continue;
+        for (int j = 0; j < NCT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    bf16* dm = Dm[wave];
+    bf16* xb = Xb[wave];
+    // every wave owns whole chunks: no workgroup barriers, only wave-local LDS traffic
+    const long wstride = (long)gridDim.x * 4;
+    for (long ck = (long)blockIdx.x * 4 + wave; ck < n_chunks; ck += wstride) {
+        const long p0 = ck * 32;
+        // lane -> (position lane>>1, tap half lane&1): builds 16 taps of one position of Dm
+        {
+            const int pl = lane >> 1, th = lane & 1;
+            const long m = p0 + pl;
+            bf16 vals[16];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int w = p.w - (kw - 1);
-                if (w < 0 || w >= gm.W) continue;
-                const long mo = m - (long)(kt - 1) * plane - (long)(kh - 1) * gm.W - (kw - 1);
-                acc += sw[c * 27 + (kt * 3 + kh) * 3 + kw] * dpre[mo * 2 + g];
+            for (int k = 0; k < 16; ++k) vals[k] = (bf16)0.f;
+            if (m < gm.M) {
+                const int w_ = (int)(m % W); long r = m / W;
+                const int h_ = (int)(r % H); r /= H;
+                const int t_ = (int)(r % T);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int tap = th * 16 + k;
+                    if (tap < 27) {
+                        const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        // xbr at p contributes to output position p - (k - 1)
+                        const int to = t_ - (kt - 1), ho = h_ - (kh - 1), wo = w_ - (kw - 1);
+                        if (to >= 0 && to < T && ho >= 0 && ho < H && wo >= 0 && wo < W)
+                            vals[k] = (bf16)dpre[(m - (long)(kt - 1) * plane - (long)(kh - 1) * W - (kw - 1)) * 2 + grp];
+                    }
+                }
+                if (th == 0) bsum += dpre[m * 2 + grp];
             }
+            bf16x8* dst = reinterpret_cast<bf16x8*>(dm + rho32(pl) * 48 + th * 16);
+            bf16x8 v0, v1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v0[k] = vals[k]; v1[k] = vals[8 + k]; }
+            dst[0] = v0; dst[1] = v1;
+        }
+        // Xb: relu(bn(x)) for 32 positions x CP channels, 8 channels per item
+        for (int i = lane; i < 32 * (CP / 8); i += 64) {
+            const int pl = i / (CP / 8), c0 = (i % (CP / 8)) * 8;
+            const long m = p0 + pl;
+            bf16x8 v = zero8();
+            if (m < gm.M && c0 < half) {
+                if (half >= 8) {
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(Xc + m * fold + grp * half + c0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (bf16)fmaxf((float)x[k] * scale[grp * half + c0 + k] + shift[grp * half + c0 + k], 0.f);
+                } else {        // half == 4
+                    const bf16x4 x = *reinterpret_cast<const bf16x4*>(Xc + m * fold + grp * half);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = (bf16)fmaxf((float)x[k] * scale[grp * half + k] + shift[grp * half + k], 0.f);
+                }
+            }
+            *reinterpret_cast<bf16x8*>(xb + rho32(pl) * LDX + c0) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int r_lo = rho32(8 * fq + (fr >> 2)), r_hi = rho32(8 * fq + (fr >> 2) + 4);
+        const int cc = 4 * (fr & 3);
+        bf16x8 fa[2], fb[NCT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + r_lo * 48 + i * 16 + cc));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + r_hi * 48 + i * 16 + cc));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + r_lo * LDX + j * 16 + cc));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + r_hi * LDX + j * 16 + cc));
+            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // D[row = tap (fq*4 + r)][col = channel (fr)]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tap = i * 16 + fq * 4 + r, c = j * 16 + fr;
+                if (tap < 27 && c < half) atomicAdd(dw + ((long)(grp * half + c)) * 27 + tap, acc[i][j][r]);
+            }
+    bsum = wave_sum(bsum);
+    if (lane == 0) atomicAdd(db + grp, bsum);
+}
+
+// ------------------------------------------------------------------ backward: gradient at the BatchNorm3d output
+// dxbn[m,c] = [bn(x) > 0] * sum_tap w[c][tap] * dpre[m - off(tap), g]   -> bf16 [M][fold]
+// workgroup = (row tile, frame, clip*2+group); dpre halo tile in LDS; thread = position, taps in registers,
+// weights [c][27] wave-uniform (scalar loads)
+template <int V>
+__global__ __launch_bounds__(256) void gsm_dxbn_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ w3d, bf16* __restrict__ dxbn, Geom gm, int TH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
+    float* tile = (float*)smem;                            // [3][TH+2][W+2]
+    const int fold = gm.fold, half = fold >> 1;
+    const int grp = blockIdx.z & 1, b = blockIdx.z >> 1, t = blockIdx.y, h0 = blockIdx.x * TH;
+    const int W = gm.W, H = gm.H, W2 = W + 2, rows = TH + 2;
+    const long plane = (long)H * W;
+    const int items = 3 * rows * W2;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int wp = i % W2; int r = i / W2;
+        const int hr = r % rows, kt = r / rows;
+        const int tt = t + kt - 1, hh = h0 + hr - 1, ww = wp - 1;
+        float v = 0.f;
+        if (tt >= 0 && tt < gm.T && hh >= 0 && hh < H && ww >= 0 && ww < W)
+            v = dpre[(((long)(b * gm.T + tt)) * plane + (long)hh * W + ww) * 2 + grp];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const float* wg = w3d + (long)grp * half * 27;         // [half][27]
+    const float* sc = scale + grp * half;
+    const float* sh = shift + grp * half;
+    const int nout = TH * W;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int hr = o / W, ww = o - hr * W;
+        const int hh = h0 + hr;
+        if (hh >= H) continue;
+        float dp[27];
+        // output position q = p - (k-1) <=> tile index (1 - (kt-1), hr + 1 - (kh-1), ww + 1 - (kw-1))
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    dp[(kt * 3 + kh) * 3 + kw] = tile[((2 - kt) * rows + hr + 2 - kh) * W2 + ww + 2 - kw];
+        const long m = ((long)(b * gm.T + t)) * plane + (long)hh * W + ww;
+        const bf16* xrow = Xc + m * fold + grp * half;
+        bf16* orow = dxbn + m * fold + grp * half;
+        for (int c = 0; c < half; c += V) {
+            const vecb x = *reinterpret_cast<const vecb*>(xrow + c);
+            vecb o8;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float* wc = wg + (c + k) * 27;
+                float a = 0.f;
+#pragma unroll
+                for (int tp = 0; tp < 27; ++tp) a += wc[tp] * dp[tp];
+                const float xbn = (float)x[k] * sc[c + k] + sh[c + k];
+                o8[k] = (bf16)(xbn > 0.f ? a : 0.f);
+            }
+            *reinterpret_cast<vecb*>(orow + c) = o8;
         }
     }
-    return acc;
 }
 
-// s_dy[c] += sum dxbn, s_dyx[c] += sum dxbn * x       (thread per (row, channel), channel fixed per thread)
-__global__ __launch_bounds__(256) void gsm_bwd_bnreduce_kernel(const float* __restrict__ dpre, const bf16* __restrict__ X,
-                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               const float* __restrict__ w3d, float* s_dy, float* s_dyx, Geom gm) {
-    extern __shared__ float lds[];     // w[fold*27] + acc[2*fold]
-    const int fold = gm.fold, half = fold >> 1;
-    float* sw = lds; float* sa = lds + fold * 27;
-    for (int i = threadIdx.x; i < fold * 27; i += blockDim.x) sw[i] = w3d[i];
-    for (int i = threadIdx.x; i < 2 * fold; i += blockDim.x) sa[i] = 0.f;
-    __syncthreads();
+// ------------------------------------------------------------------ backward: input gradient (elementwise)
+// dXf[m,c] = dG[m,c] + gate[m,g]*(dG[m -+ plane, c] - dG[m,c]) + alpha[c]*dxbn[m,c] + beta[c]*x[m,c] + delta[c]
+template <int V>
+__global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict__ dG, const bf16* __restrict__ Xc,
+                                                         const float* __restrict__ gate, const bf16* __restrict__ dxbn,
+                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                         const float* __restrict__ delta, bf16* __restrict__ dXf, Geom gm) {
+    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
+    const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
-    const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, TT = (long)gridDim.x * blockDim.x;
-    const int c = (int)(gt % fold), g = c / half;
-    const float s = scale[c], b = shift[c];
-    float a0 = 0.f, a1 = 0.f;
-    for (long m = gt / fold; m < gm.M; m += TT / fold) {
-        const Pos p = decode(m, gm);
-        const float x = (float)X[m * gm.ldx + c];
-        const float d = dxbn_at(m, c, g, p, dpre, sw, x * s + b, gm, plane);
-        a0 += d; a1 += d * x;
-    }
-    atomicAdd(&sa[c], a0); atomicAdd(&sa[fold + c], a1);
-    __syncthreads();
-    for (int i = threadIdx.x; i < fold; i += blockDim.x) { atomicAdd(s_dy + i, sa[i]); atomicAdd(s_dyx + i, sa[fold + i]); }
-}
-
-// dXf[m,c] = dG[m,dest] + gate[m,g]*(dG[m -+ plane, dest] - dG[m, dest]) + alpha*dxbn + beta*x + delta
-__global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict__ dG, long ldg, const bf16* __restrict__ X,
-                                                         const float* __restrict__ gate, const float* __restrict__ dpre,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ w3d, const float* __restrict__ alpha,
-                                                         const float* __restrict__ beta, const float* __restrict__ delta,
-                                                         bf16* __restrict__ dXf, Geom gm) {
-    extern __shared__ float lds[];
-    const int fold = gm.fold, half = fold >> 1;
-    float* sw = lds;
-    for (int i = threadIdx.x; i < fold * 27; i += blockDim.x) sw[i] = w3d[i];
-    __syncthreads();
-    const long plane = (long)gm.H * gm.W;
-    const long total = gm.M * fold;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / fold; const int c = (int)(i - m * fold);
-        const int g = c / half, d = dest_of(c, fold);
-        const Pos p = decode(m, gm);
-        const float x = (float)X[m * gm.ldx + c];
-        const float dr = (float)dG[m * ldg + d];
-        const int tp = g == 0 ? p.t - 1 : p.t + 1;
-        float dyt = -dr;
-        if (tp >= 0 && tp < gm.T) dyt += (float)dG[(g == 0 ? m - plane : m + plane) * ldg + d];
-        float v = dr + dyt * gate[m * 2 + g];
-        const float dbn = dxbn_at(m, c, g, p, dpre, sw, x * scale[c] + shift[c], gm, plane);
-        v += alpha[c] * dbn + beta[c] * x + delta[c];
-        dXf[m * fold + c] = (bf16)v;
+    const long total = gm.M * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nch; const int c0 = (int)(i - m * nch) * V;
+        const int g = c0 >= half;
+        const int t = (int)((m / plane) % gm.T);
+        const int tp = g == 0 ? t - 1 : t + 1;
+        const bool has = tp >= 0 && tp < gm.T;
+        const long mp = g == 0 ? m - plane : m + plane;
+        const vecb d0 = *reinterpret_cast<const vecb*>(dG + m * fold + c0);
+        const vecb x = *reinterpret_cast<const vecb*>(Xc + m * fold + c0);
+        const vecb db = *reinterpret_cast<const vecb*>(dxbn + m * fold + c0);
+        vecb d1;
+        if (has) d1 = *reinterpret_cast<const vecb*>(dG + mp * fold + c0);
+        const float gt = gate[m * 2 + g];
+        vecb o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float dr = (float)d0[k];
+            const float dyt = (has ? (float)d1[k] : 0.f) - dr;
+            o[k] = (bf16)(dr + dyt * gt + alpha[c0 + k] * (float)db[k] + beta[c0 + k] * (float)x[k] + delta[c0 + k]);
+        }
+        *reinterpret_cast<vecb*>(dXf + m * fold + c0) = o;
     }
 }
 
-// ------------------------------------------------------------------ column statistics of a slice
-__global__ __launch_bounds__(256) void col_stats_kernel(const bf16* __restrict__ X, long ldx, int ncols, long M, float* sum, float* sumsq) {
+// ------------------------------------------------------------------ column statistics / slice copy of a strided tensor
+__global__ __launch_bounds__(256) void col_stats_kernel(const bf16* __restrict__ X, long ldx, int ncols, long M, float* sum, float* sumsq,
+                                                        bf16* __restrict__ copy) {
     extern __shared__ float lds[];
     for (int i = threadIdx.x; i < 2 * ncols; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
     const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, TT = (long)gridDim.x * blockDim.x;
     const int c = (int)(gt % ncols);
     float a = 0.f, b = 0.f;
-    for (long m = gt / ncols; m < M; m += TT / ncols) { const float v = (float)X[m * ldx + c]; a += v; b += v * v; }
-    atomicAdd(&lds[c], a); atomicAdd(&lds[ncols + c], b);
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncols; i += blockDim.x) { atomicAdd(sum + i, lds[i]); atomicAdd(sumsq + i, lds[ncols + i]); }
+    for (long m = gt / ncols; m < M; m += TT / ncols) {
+        const bf16 xv = X[m * ldx + c];
+        if (copy) copy[m * ncols + c] = xv;
+        const float v = (float)xv; a += v; b += v * v;
+    }
+    if (sum) {
+        atomicAdd(&lds[c], a); atomicAdd(&lds[ncols + c], b);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncols; i += blockDim.x) { atomicAdd(sum + i, lds[i]); atomicAdd(sumsq + i, lds[ncols + i]); }
+    }
 }
 
 // ------------------------------------------------------------------ plain temporal shift (TSM)
@@ -268,7 +420,6 @@ __global__ __launch_bounds__(256) void tsm_shift_kernel(const bf16* __restrict__
 }
 
 int flat_blocks(long total, int tpb, int ncols) {
-    // grid*tpb must be a multiple of ncols
     int a = ncols, b = tpb;
     while (b) { int t = a % b; a = b; b = t; }
     const int unit = ncols / a;
@@ -280,99 +431,141 @@ int flat_blocks(long total, int tpb, int ncols) {
 
 int check_geom(const stes_gsm_geom* g) {
     STES_CHECK(g && g->B > 0 && g->T > 0 && g->H > 0 && g->W > 0, STES_ERR_ARG, "gsm: bad geometry");
-    STES_CHECK(g->fold >= 4 && g->fold % 4 == 0 && g->fold <= g->ldx, STES_ERR_ARG, "gsm: fold must be a positive multiple of 4, at most the row stride");
+    STES_CHECK(g->fold == 8 || (g->fold >= 16 && g->fold % 16 == 0), STES_ERR_ARG, "gsm: fold must be 8 or a multiple of 16");
+    STES_CHECK(g->fold <= 192, STES_ERR_ARG, "gsm: fold > 192 is not built");
     return STES_OK;
 }
 
 Geom to_geom(const stes_gsm_geom* g) {
     Geom gm;
-    gm.B = g->B; gm.T = g->T; gm.H = g->H; gm.W = g->W; gm.ldx = g->ldx; gm.fold = g->fold;
+    gm.B = g->B; gm.T = g->T; gm.H = g->H; gm.W = g->W; gm.fold = g->fold;
     gm.M = (long)g->B * g->T * g->H * g->W;
     return gm;
+}
+
+// rows per tile so that the halo tile stays under ~48 KiB
+int tile_rows(const Geom& gm, int bytes_per_pos) {
+    int th = gm.H;
+    while (th > 1 && 3L * (th + 2) * (gm.W + 2) * bytes_per_pos > 48 * 1024) th = (th + 1) / 2;
+    return th;
 }
 
 }  // namespace
 
 #define S(s) ((hipStream_t)(s))
 
-extern "C" int stes_gsm_gate(const uint16_t* X, const float* scale, const float* shift, const float* w3d, const float* b3d,
+extern "C" int stes_gsm_prep(const float* w3d, float* wt, int fold, void* stream) {
+    STES_CHECK(w3d && wt && fold >= 8, STES_ERR_ARG, "stes_gsm_prep: bad argument");
+    const int n = fold * 27;
+    hipLaunchKernelGGL(gsm_prep_kernel, dim3(stes_div_up(n, 256)), dim3(256), 0, S(stream), w3d, wt, fold / 2);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const float* wt, const float* b3d,
                              float* gate, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(X && scale && shift && w3d && b3d && gate, STES_ERR_ARG, "stes_gsm_gate: null pointer");
-    STES_CHECK(g->fold % 8 == 0 && g->ldx % 4 == 0, STES_ERR_ARG, "stes_gsm_gate: fold % 8, ldx % 4");
+    STES_CHECK(Xc && scale && shift && wt && b3d && gate, STES_ERR_ARG, "stes_gsm_gate: null pointer");
     const Geom gm = to_geom(g);
     const int half = gm.fold / 2;
-    long blocks = (gm.M + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gsm_gate_kernel, dim3((int)blocks, 2), dim3(256), (size_t)(half * 29) * sizeof(float), S(stream), (const bf16*)X,
-                       scale, shift, w3d, b3d, gate, gm);
+    const int th = tile_rows(gm, half * 2);
+    const size_t lds = (size_t)3 * (th + 2) * (gm.W + 2) * half * 2;
+    STES_CHECK(lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_gate: image row too wide for the LDS tile");
+    const dim3 grid(stes_div_up(gm.H, th), gm.T, gm.B * 2);
+    if (half == 4)
+        hipLaunchKernelGGL(gsm_gate_kernel<4>, grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, wt, b3d, gate, gm, th);
+    else
+        hipLaunchKernelGGL(gsm_gate_kernel<8>, grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, wt, b3d, gate, gm, th);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_shift(const uint16_t* X, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream) {
+extern "C" int stes_gsm_shift(const uint16_t* Xc, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(X && gate && G, STES_ERR_ARG, "stes_gsm_shift: null pointer");
+    STES_CHECK(Xc && gate && G, STES_ERR_ARG, "stes_gsm_shift: null pointer");
     const Geom gm = to_geom(g);
-    long blocks = (gm.M * gm.fold + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gsm_shift_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)X, gate, (bf16*)G, gm);
+    const int V = gm.fold == 8 ? 4 : 8;
+    long blocks = (gm.M * (gm.fold / V) + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (V == 4) hipLaunchKernelGGL(gsm_shift_kernel<4>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)Xc, gate, (bf16*)G, gm);
+    else hipLaunchKernelGGL(gsm_shift_kernel<8>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)Xc, gate, (bf16*)G, gm);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_bwd_gate(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, float* dpre,
+extern "C" int stes_gsm_bwd_gate(const uint16_t* dG, const uint16_t* Xc, const float* gate, float* dpre,
                                  const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(dG && X && gate && dpre && ldg >= g->fold, STES_ERR_ARG, "stes_gsm_bwd_gate: bad argument");
+    STES_CHECK(dG && Xc && gate && dpre, STES_ERR_ARG, "stes_gsm_bwd_gate: bad argument");
     const Geom gm = to_geom(g);
     long blocks = (gm.M * 2 + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gsm_bwd_gate_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (long)ldg, (const bf16*)X, gate, dpre, gm);
+    if (gm.fold == 8) hipLaunchKernelGGL(gsm_bwd_gate_kernel<4>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate, dpre, gm);
+    else hipLaunchKernelGGL(gsm_bwd_gate_kernel<8>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate, dpre, gm);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* X, const float* scale, const float* shift, float* dw,
+extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, float* dw,
                                   float* db, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(dpre && X && scale && shift && dw && db, STES_ERR_ARG, "stes_gsm_bwd_wgrad: null pointer");
+    STES_CHECK(dpre && Xc && scale && shift && dw && db, STES_ERR_ARG, "stes_gsm_bwd_wgrad: null pointer");
     const Geom gm = to_geom(g);
-    int rows = (int)((gm.M + 1023) / 1024);
-    if (rows < 64) rows = 64;
-    const int blocks = stes_div_up(gm.M, rows);
-    hipLaunchKernelGGL(gsm_bwd_wgrad_kernel, dim3(blocks), dim3(256), 0, S(stream), dpre, (const bf16*)X, scale, shift, dw, db, gm, rows);
+    const int half = gm.fold / 2;
+    const long n_chunks = (gm.M + 31) / 32;
+    long gx = (n_chunks + 3) / 4; if (gx > 1024) gx = 1024;
+    const dim3 grid((int)gx, 2);
+    const int nct = (half + 15) / 16;
+#define LAUNCH_WG(N) hipLaunchKernelGGL(gsm_bwd_wgrad_kernel<N>, grid, dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks)
+    switch (nct) {
+        case 1: LAUNCH_WG(1); break;
+        case 2: LAUNCH_WG(2); break;
+        case 3: LAUNCH_WG(3); break;
+        case 4: LAUNCH_WG(4); break;
+        case 5: LAUNCH_WG(5); break;
+        default: LAUNCH_WG(6); break;
+    }
+#undef LAUNCH_WG
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_bwd_bnreduce(const float* dpre, const uint16_t* X, const float* scale, const float* shift, const float* w3d,
-                                     float* s_dy, float* s_dyx, const stes_gsm_geom* g, void* stream) {
+extern "C" int stes_gsm_dxbn(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d,
+                             uint16_t* dxbn, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(dpre && X && scale && shift && w3d && s_dy && s_dyx, STES_ERR_ARG, "stes_gsm_bwd_bnreduce: null pointer");
+    STES_CHECK(dpre && Xc && scale && shift && w3d && dxbn, STES_ERR_ARG, "stes_gsm_dxbn: null pointer");
     const Geom gm = to_geom(g);
-    const int blocks = flat_blocks(gm.M * gm.fold, 256, gm.fold);
-    hipLaunchKernelGGL(gsm_bwd_bnreduce_kernel, dim3(blocks), dim3(256), (size_t)(gm.fold * 29) * sizeof(float), S(stream), dpre, (const bf16*)X,
-                       scale, shift, w3d, s_dy, s_dyx, gm);
+    const int th = tile_rows(gm, 4);
+    const size_t lds = (size_t)3 * (th + 2) * (gm.W + 2) * 4;
+    const dim3 grid(stes_div_up(gm.H, th), gm.T, gm.B * 2);
+    if (gm.fold == 8)
+        hipLaunchKernelGGL(gsm_dxbn_kernel<4>, grid, dim3(256), lds, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d, (bf16*)dxbn, gm, th);
+    else
+        hipLaunchKernelGGL(gsm_dxbn_kernel<8>, grid, dim3(256), lds, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d, (bf16*)dxbn, gm, th);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_bwd_dx(const uint16_t* dG, int64_t ldg, const uint16_t* X, const float* gate, const float* dpre,
-                               const float* scale, const float* shift, const float* w3d, const float* alpha, const float* beta,
-                               const float* delta, uint16_t* dXf, const stes_gsm_geom* g, void* stream) {
+extern "C" int stes_gsm_bwd_dx(const uint16_t* dG, const uint16_t* Xc, const float* gate, const uint16_t* dxbn,
+                               const float* alpha, const float* beta, const float* delta, uint16_t* dXf, const stes_gsm_geom* g,
+                               void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(dG && X && gate && dpre && scale && shift && w3d && alpha && beta && delta && dXf, STES_ERR_ARG, "stes_gsm_bwd_dx: null pointer");
+    STES_CHECK(dG && Xc && gate && dxbn && alpha && beta && delta && dXf, STES_ERR_ARG, "stes_gsm_bwd_dx: null pointer");
     const Geom gm = to_geom(g);
-    long blocks = (gm.M * gm.fold + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gsm_bwd_dx_kernel, dim3((int)blocks), dim3(256), (size_t)(gm.fold * 27) * sizeof(float), S(stream), (const bf16*)dG,
-                       (long)ldg, (const bf16*)X, gate, dpre, scale, shift, w3d, alpha, beta, delta, (bf16*)dXf, gm);
+    const int V = gm.fold == 8 ? 4 : 8;
+    long blocks = (gm.M * (gm.fold / V) + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (V == 4) hipLaunchKernelGGL(gsm_bwd_dx_kernel<4>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate,
+                                   (const bf16*)dxbn, alpha, beta, delta, (bf16*)dXf, gm);
+    else hipLaunchKernelGGL(gsm_bwd_dx_kernel<8>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate,
+                            (const bf16*)dxbn, alpha, beta, delta, (bf16*)dXf, gm);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, void* stream) {
-    STES_CHECK(X && sum && sumsq && ncols > 0 && ncols <= ldx && M > 0, STES_ERR_ARG, "stes_col_stats: bad argument");
+extern "C" int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, uint16_t* copy,
+                              void* stream) {
+    STES_CHECK(X && ncols > 0 && ncols <= ldx && M > 0 && (sum == nullptr) == (sumsq == nullptr) && (sum || copy), STES_ERR_ARG, "stes_col_stats: bad argument");
     const int blocks = flat_blocks(M * ncols, 256, ncols);
     hipLaunchKernelGGL(col_stats_kernel, dim3(blocks), dim3(256), (size_t)(2 * ncols) * sizeof(float), S(stream), (const bf16*)X, (long)ldx,
-                       ncols, (long)M, sum, sumsq);
+                       ncols, (long)M, sum, sumsq, (bf16*)copy);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

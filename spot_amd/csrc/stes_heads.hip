@@ -269,13 +269,25 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 // ------------------------------------------------------------------ fp32 -> bf16 weight copies
 // dst[r][c] = src[r][c] (transpose = 0) or dst[c][r] = src[r][c] (transpose = 1); dst rows padded with zeros to ld
-__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ld, int dst_rows, int transpose) {
+// perm_fold > 0: the first perm_fold source COLUMNS are read through the gated shift's channel interleave, i.e. destination
+// column c takes source column dest(c) (reference model/shift.py:124-128), so the consumer can keep source channel order
+__device__ __forceinline__ int gsm_dest(int c, int fold) {
+    const int half = fold >> 1, quarter = fold >> 2;
+    const int g = c / half, rem = c - g * half;
+    const int i = rem / quarter, j = rem - i * quarter;
+    return g * half + 2 * j + i;
+}
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ld, int dst_rows, int transpose,
+                                 int perm_fold) {
     const long total = (long)dst_rows * ld;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int dr = (int)(i / ld), dc = (int)(i - (long)dr * ld);
         float v = 0.f;
-        if (!transpose) { if (dr < rows && dc < cols) v = src[(long)dr * cols + dc]; }
-        else { if (dc < rows && dr < cols) v = src[(long)dc * cols + dr]; }
+        if (!transpose) {
+            if (dr < rows && dc < cols) v = src[(long)dr * cols + (dc < perm_fold ? gsm_dest(dc, perm_fold) : dc)];
+        } else {
+            if (dc < rows && dr < cols) v = src[(long)dc * cols + (dr < perm_fold ? gsm_dest(dr, perm_fold) : dr)];
+        }
         dst[i] = (bf16)v;
     }
 }
@@ -354,11 +366,12 @@ extern "C" int stes_adamw(float* p, const float* g, float* m, float* v, int64_t 
     return STES_OK;
 }
 
-extern "C" int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, void* stream) {
+extern "C" int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, int perm_fold,
+                              void* stream) {
     STES_CHECK(src && dst && rows > 0 && cols > 0, STES_ERR_ARG, "stes_cast_bf16: bad argument");
     STES_CHECK(transpose ? (ld >= rows && dst_rows >= cols) : (ld >= cols && dst_rows >= rows), STES_ERR_ARG, "stes_cast_bf16: destination too small");
     long blocks = ((long)dst_rows * ld + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, S(stream), src, (bf16*)dst, rows, cols, ld, dst_rows, transpose);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, S(stream), src, (bf16*)dst, rows, cols, ld, dst_rows, transpose, perm_fold);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -63,7 +63,7 @@ class BN:
 class Linear:
     """nn.Linear / 1x1 conv weight with its bf16 copy [N][K] and transposed copy [K][N8]."""
 
-    def __init__(self, eng, weight, bias=None, n=None, k=None, kp=None):
+    def __init__(self, eng, weight, bias=None, n=None, k=None, kp=None, perm_fold=0):
         self.w, self.b = weight, bias
         self.N = n if n is not None else weight.shape[0]
         self.K = k if k is not None else weight[0].numel()
@@ -71,8 +71,8 @@ class Linear:
         self.Np = _rup(self.N, 8)
         self.w_bf = eng.bf16(self.N, self.Kp)
         self.wT_bf = eng.bf16(self.Kp, self.Np)
-        eng.casts.append((weight, self.w_bf, self.N, self.K, self.Kp, self.N, 0))
-        eng.casts.append((weight, self.wT_bf, self.N, self.K, self.Np, self.Kp, 1))
+        eng.casts.append((weight, self.w_bf, self.N, self.K, self.Kp, self.N, 0, perm_fold))
+        eng.casts.append((weight, self.wT_bf, self.N, self.K, self.Np, self.Kp, 1, perm_fold))
 
 
 class Block:
@@ -85,7 +85,13 @@ class Block:
         self.cout = blk.conv3.conv.out_channels
         if blk.conv2.conv.in_channels // blk.conv2.conv.groups != 16 or self.cmid % 64:
             raise NotImplementedError("grouped 3x3 conv kernel is built for group width 16 and channels % 64 == 0 (regnety_008)")
-        self.l1 = Linear(eng, conv1.conv.weight)
+        self.fold = 0
+        if self.kind == "gsm":
+            self.fold = c1.fold_dim
+            if not (self.fold == 8 or self.fold % 16 == 0) or self.fold > 192:
+                raise NotImplementedError("gated shift kernels are built for fold 8 or a multiple of 16, up to 192")
+        # the gated-shift output keeps the source channel order: conv1's input columns are permuted instead
+        self.l1 = Linear(eng, conv1.conv.weight, perm_fold=self.fold)
         self.l3 = Linear(eng, blk.conv3.conv.weight)
         self.bn1, self.bn2, self.bn3 = BN(eng, conv1.bn), BN(eng, blk.conv2.bn), BN(eng, blk.conv3.bn)
         self.w2 = blk.conv2.conv.weight
@@ -98,13 +104,11 @@ class Block:
         if self.down:
             self.ld = Linear(eng, blk.downsample.conv.weight)
             self.bnd = BN(eng, blk.downsample.bn)
-        self.fold = 0
         if self.kind == "gsm":
-            self.fold = c1.fold_dim
-            if self.fold % 8:
-                raise NotImplementedError("gated shift kernels need fold % 8 == 0")
             self.gsm = c1.gsm
             self.bng = BN(eng, c1.gsm.bn)
+            self.wt = torch.zeros(27 * self.fold, device=eng.dev)
+            eng.gsm_preps.append((c1.gsm.conv3D.weight, self.wt, self.fold))
         elif self.kind == "tsm":
             self.tsm_fold = self.cin // c1.fold_div
 
@@ -118,6 +122,7 @@ class Block:
         a = e.act
         nm = self.name
         if self.kind == "gsm":
+            self.Xc = a(nm + ".Xc", self.Mi * self.fold, BF)
             self.G = a(nm + ".G", self.Mi * self.fold, BF)
             self.gate = a(nm + ".gate", self.Mi * 2, F32)
         elif self.kind == "tsm":
@@ -134,7 +139,8 @@ class Block:
         return self.Ho, self.Wo
 
     # ------------------------------------------------------------------ forward
-    def forward(self, X, train, next_fold, next_stats):
+    def forward(self, X, train, nxt):
+        """nxt: the next block when it has a gated shift (its fold slice copy and BatchNorm3d sums are produced here)."""
         e = self.eng
         p = lib.ptr
         Mi, Mo, cin, cmid, cout = self.Mi, self.Mo, self.cin, self.cmid, self.cout
@@ -142,12 +148,12 @@ class Block:
         self.X = X
         a_src, a0, k0 = X, None, 0
         if self.kind == "gsm":
-            geom = lib.gsm_geom(self.N // self.T, self.T, self.Hi, self.Wi, cin, self.fold)
+            geom = lib.gsm_geom(self.N // self.T, self.T, self.Hi, self.Wi, self.fold)
             self.geom = geom
             self.bng.finalize(Mi, train)
-            w3d, b3d = self.gsm.conv3D.weight, self.gsm.conv3D.bias
-            lib.call("stes_gsm_gate", p(X), p(self.bng.scale), p(self.bng.shift), p(w3d), p(b3d), p(self.gate), C.byref(geom))
-            lib.call("stes_gsm_shift", p(X), p(self.gate), p(self.G), C.byref(geom))
+            lib.call("stes_gsm_gate", p(self.Xc), p(self.bng.scale), p(self.bng.shift), p(self.wt), p(self.gsm.conv3D.bias), p(self.gate),
+                     C.byref(geom))
+            lib.call("stes_gsm_shift", p(self.Xc), p(self.gate), p(self.G), C.byref(geom))
             a0, k0 = self.G, self.fold
         elif self.kind == "tsm":
             lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
@@ -167,7 +173,6 @@ class Block:
         lib.gemm(self.c2, self.l3.w_bf, self.c3, Mo, cout, cmid, scale=self.bn2.scale, shift=self.bn2.shift, relu=True,
                  gate=self.segate, gate_group=HWo, stats=st(self.bn3))
         self.bn3.finalize(Mo, train)
-        ns = next_stats if train else None
         if self.down:
             rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
             lib.gemm(a_src, self.ld.w_bf, self.sc, Mo, cout, cin, rowmap=rowmap, stats=st(self.bnd))
@@ -175,8 +180,7 @@ class Block:
             res, rs, rb = self.sc, self.bnd.scale, self.bnd.shift
         else:
             res, rs, rb = a_src, None, None
-        lib.call("stes_bn_act_residual", p(self.c3), p(self.bn3.scale), p(self.bn3.shift), p(res), p(rs), p(rb), p(self.out),
-                 p(ns[0]) if ns else None, p(ns[1]) if ns else None, next_fold if ns else 0, Mo, cout)
+        e.bn_act(self.c3, self.bn3, res, rs, rb, self.out, nxt, train, Mo, cout)
         return self.out
 
     # ------------------------------------------------------------------ backward
@@ -228,20 +232,22 @@ class Block:
         lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1, **kw1)
         # --- conv1 (1x1)
         q0, k0 = (self.G, self.fold) if self.kind == "gsm" else (None, 0)
-        lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0)
+        lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold)
         dY1 = sc("dY1", Mi * cin)
-        lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, ldw=self.l1.Np)
+        dG = sc("gsm.dG", Mi * self.fold) if self.kind == "gsm" else None
+        lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, ldw=self.l1.Np, C0=dG, ldc0=self.fold, n_split=self.fold)
         dXf = None
         if self.kind == "gsm":
-            gs, bng, geom = self.gsm, self.bng, self.geom
+            gs, bng, geom, Xc, fold = self.gsm, self.bng, self.geom, self.Xc, self.fold
             dpre = sc("gsm.dpre", Mi * 2, F32)
-            lib.call("stes_gsm_bwd_gate", p(dY1), cin, p(X), p(self.gate), p(dpre), C.byref(geom))
-            lib.call("stes_gsm_bwd_wgrad", p(dpre), p(X), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), C.byref(geom))
-            lib.call("stes_gsm_bwd_bnreduce", p(dpre), p(X), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(bng.s_dy), p(bng.s_dyr), C.byref(geom))
+            lib.call("stes_gsm_bwd_gate", p(dG), p(Xc), p(self.gate), p(dpre), C.byref(geom))
+            lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), C.byref(geom))
+            dxbn = sc("gsm.dxbn", Mi * fold)
+            lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), C.byref(geom))
+            lib.bn_bwd_reduce(dxbn, Xc, Mi, fold, [bng.s_dy, bng.s_dyr])
             bng.bwd_finalize(Mi)
-            dXf = sc("gsm.dXf", Mi * self.fold)
-            lib.call("stes_gsm_bwd_dx", p(dY1), cin, p(X), p(self.gate), p(dpre), p(bng.scale), p(bng.shift), p(gs.conv3D.weight),
-                     p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
+            dXf = sc("gsm.dXf", Mi * fold)
+            lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(self.gate), p(dxbn), p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
         elif self.kind == "tsm":
             dY1s = sc("tsm.dY1s", Mi * cin)
             lib.call("stes_tsm_shift", p(dY1), p(dY1s), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
@@ -283,8 +289,8 @@ class GRULayer:
         self.lin = Linear(eng, self.wih_all, n=6 * H, k=in_dim)
         self.whh_bf, self.whhT_bf = eng.bf16(2, 3 * H, H), eng.bf16(2, H, 3 * H)
         for d in range(2):
-            eng.casts.append((self.whh[d], self.whh_bf[d], 3 * H, H, H, 3 * H, 0))
-            eng.casts.append((self.whh[d], self.whhT_bf[d], 3 * H, H, 3 * H, H, 1))
+            eng.casts.append((self.whh[d], self.whh_bf[d], 3 * H, H, H, 3 * H, 0, 0))
+            eng.casts.append((self.whh[d], self.whhT_bf[d], 3 * H, H, 3 * H, H, 1, 0))
 
 
 class Engine:
@@ -296,7 +302,7 @@ class Engine:
             raise lib.StesError("spot_amd runs on an MI355X through libstes_hip; the model must be on a cuda (ROCm) device")
         lib.lib()
         self.impl, self.dev, self.clip_len = impl, dev, clip_len
-        self.casts, self.packs = [], []
+        self.casts, self.packs, self.gsm_preps = [], [], []
         self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
         self._stats_used = 0
         self._scratch, self._acts, self._pp = {}, {}, {}
@@ -357,6 +363,17 @@ class Engine:
             t = torch.empty(numel, dtype=dtype, device=self.dev)
             self._acts[name] = t
         return t
+
+    def bn_act(self, c, bn, res, rs, rb, out, nxt, train, M, Cc):
+        """out = relu(bn(c) + residual); for a following gated-shift block also its compact fold slice and, in training,
+        the BatchNorm3d sums of that slice."""
+        p = lib.ptr
+        fold, ssum, ssq, slc = 0, None, None, None
+        if nxt is not None and nxt.kind == "gsm":
+            fold, slc = nxt.fold, nxt.Xc
+            if train:
+                ssum, ssq = nxt.bng.sum, nxt.bng.sumsq
+        lib.call("stes_bn_act_residual", p(c), p(bn.scale), p(bn.shift), p(res), p(rs), p(rb), p(out), p(ssum), p(ssq), fold, p(slc), M, Cc)
 
     # ------------------------------------------------------------------ flat parameters
     def _flatten(self):
@@ -459,8 +476,10 @@ class Engine:
     def refresh_weights(self):
         self.check_views()
         p = lib.ptr
-        for src, dst, rows, cols, ld, dst_rows, tr in self.casts:
-            lib.call("stes_cast_bf16", p(src), p(dst), rows, cols, ld, dst_rows, tr)
+        for src, dst, rows, cols, ld, dst_rows, tr, pf in self.casts:
+            lib.call("stes_cast_bf16", p(src), p(dst), rows, cols, ld, dst_rows, tr, pf)
+        for w3d, wt, fold in self.gsm_preps:
+            lib.call("stes_gsm_prep", p(w3d), p(wt), fold)
         for w, wf, wd, G in self.packs:
             lib.call("stes_pack_conv3x3g", p(w), p(wf), p(wd), G)
         self.weights_dirty = False
@@ -536,20 +555,10 @@ class Engine:
         lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
         self.bn0.finalize(self.M0, train)
         blocks = self.blocks
-
-        def next_info(i):
-            if i < len(blocks) and blocks[i].kind == "gsm":
-                return blocks[i].fold, (blocks[i].bng.sum, blocks[i].bng.sumsq)
-            return 0, None
-
-        nf, ns = next_info(0)
-        ns_t = ns if train else None
-        lib.call("stes_bn_act_residual", p(self.c0), p(self.bn0.scale), p(self.bn0.shift), None, None, None, p(self.X0),
-                 p(ns_t[0]) if ns_t else None, p(ns_t[1]) if ns_t else None, nf if ns_t else 0, self.M0, 32)
+        self.bn_act(self.c0, self.bn0, None, None, None, self.X0, blocks[0], train, self.M0, 32)
         X = self.X0
         for i, blk in enumerate(blocks):
-            nf, ns = next_info(i + 1)
-            X = blk.forward(X, train, nf, ns)
+            X = blk.forward(X, train, blocks[i + 1] if i + 1 < len(blocks) else None)
         HWl = self.Hl * self.Wl
         lib.call("stes_chan_pool", p(X), None, None, None, None, p(self.feat), N, HWl, self.feat_dim, 1.0 / HWl)
         self._last_out = X

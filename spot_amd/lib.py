@@ -36,13 +36,14 @@ GemmArgs = _struct("GemmArgs", [
     ("C", _P), ("ldc", _I64), ("c_f32", _I32),
     ("col_sum", _P), ("col_sumsq", _P),
     ("relu_mask", _P), ("ldmask", _I64),
+    ("C0", _P), ("ldc0", _I64), ("n_split", _I32),
     ("M", _I64), ("N", _I32), ("K", _I32)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
     ("q_scale", _P), ("q_shift", _P), ("q_relu", _I32), ("q_gate", _P), ("gate_group", _I32),
     ("map_stride", _I32), ("Ho", _I32), ("Wo", _I32), ("Hi", _I32), ("Wi", _I32),
-    ("dW", _P), ("lddw", _I64), ("dbias", _P),
+    ("dW", _P), ("lddw", _I64), ("dbias", _P), ("perm_fold", _I32),
     ("M", _I64), ("N1", _I32), ("N2", _I32)])
 
 BnBwdArgs = _struct("BnBwdArgs", [
@@ -53,7 +54,7 @@ BnBwdArgs = _struct("BnBwdArgs", [
     ("alpha", _P), ("beta", _P), ("delta", _P), ("out", _P),
     ("M", _I64), ("C", _I32)])
 
-GsmGeom = _struct("GsmGeom", [("B", _I32), ("T", _I32), ("H", _I32), ("W", _I32), ("ldx", _I32), ("fold", _I32)])
+GsmGeom = _struct("GsmGeom", [("B", _I32), ("T", _I32), ("H", _I32), ("W", _I32), ("fold", _I32)])
 
 GruArgs = _struct("GruArgs", [
     ("gi", _P), ("whh", _P), ("whhT", _P), ("bhh", _P),
@@ -66,7 +67,7 @@ _SIGS = {
     "stes_gemm": [_P, _P],
     "stes_wgrad": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
-    "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _P],
+    "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
     "stes_se_fc": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_se_fc_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
@@ -81,13 +82,14 @@ _SIGS = {
     "stes_conv3x3g_dgrad": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "stes_gsm_prep": [_P, _P, _I32, _P],
     "stes_gsm_gate": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stes_gsm_shift": [_P, _P, _P, _P, _P],
-    "stes_gsm_bwd_gate": [_P, _I64, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_gate": [_P, _P, _P, _P, _P, _P],
     "stes_gsm_bwd_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P],
-    "stes_gsm_bwd_bnreduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "stes_gsm_bwd_dx": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "stes_col_stats": [_P, _I64, _I32, _I64, _P, _P, _P],
+    "stes_gsm_dxbn": [_P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_col_stats": [_P, _I64, _I32, _I64, _P, _P, _P, _P],
     "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gru_forward": [_P, _P],
     "stes_gru_backward": [_P, _P],
@@ -96,7 +98,7 @@ _SIGS = {
     "stes_dropout": [_P, _P, _P, _I64, _F32, _U32, _P],
     "stes_loss": [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _F32, _F32, _P, _P, _P, _P, _P],
     "stes_adamw": [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _F32, _P],
-    "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
 }
 EXPORTS = ["stes_version", "stes_last_error"] + list(_SIGS)
 
@@ -139,7 +141,7 @@ def call(name, *args):
 # ---------------------------------------------------------------- struct-argument entry points
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
-         bias=None, act=0, stats=None, relu_mask=None, ldmask=0):
+         bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0):
     """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
@@ -154,12 +156,13 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     if stats is not None:
         a.col_sum, a.col_sumsq = ptr(stats[0]), ptr(stats[1])
     a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
+    a.C0, a.ldc0, a.n_split = ptr(C0), ldc0, n_split
     a.M, a.N, a.K = M, N, K
     check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
 
 
 def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0, k0=0,
-          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None):
+          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None, perm_fold=0):
     """dW += P^T pro(Q); see stes_wgrad in include/stes.h."""
     a = WgradArgs()
     a.P, a.ldp = ptr(P), ldp if ldp is not None else N1
@@ -170,6 +173,7 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
     if rowmap is not None:
         a.map_stride, a.Ho, a.Wo, a.Hi, a.Wi = rowmap
     a.dW, a.lddw, a.dbias = ptr(dW), lddw if lddw is not None else N2, ptr(dbias)
+    a.perm_fold = perm_fold
     a.M, a.N1, a.N2 = M, N1, N2
     check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")
 
@@ -201,9 +205,9 @@ def bn_bwd_apply(D, raw1, M, Cc, coef, out, **kw):
     check(lib().stes_bn_bwd_apply(C.byref(a), stream()), "stes_bn_bwd_apply")
 
 
-def gsm_geom(B, T, H, W, ldx, fold):
+def gsm_geom(B, T, H, W, fold):
     g = GsmGeom()
-    g.B, g.T, g.H, g.W, g.ldx, g.fold = B, T, H, W, ldx, fold
+    g.B, g.T, g.H, g.W, g.fold = B, T, H, W, fold
     return g
 
 

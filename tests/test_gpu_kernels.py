@@ -120,12 +120,14 @@ def test_bn_finalize_and_act_residual():
              0.1, 1e-5, 1, lib.ptr(scale), lib.ptr(shift), lib.ptr(mean), lib.ptr(inv), Cc)
     out = torch.empty(M, Cc, dtype=BF, device="cuda")
     st1 = torch.zeros(16, device="cuda"); st2 = torch.zeros(16, device="cuda")
+    slc = torch.zeros(M, 16, dtype=BF, device="cuda")
     lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), lib.ptr(dev(res)), None, None, lib.ptr(out),
-             lib.ptr(st1), lib.ptr(st2), 16, M, Cc)
+             lib.ptr(st1), lib.ptr(st2), 16, lib.ptr(slc), M, Cc)
     torch.cuda.synchronize()
     close(out, ref.detach(), 1e-2, 1e-2)
     close(rmd, bn.running_mean, 1e-5, 1e-5); close(rvd, bn.running_var, 1e-4, 1e-5)
     close(st1, out.float()[:, :16].sum(0), 1e-4, 1e-3); close(st2, (out.float()[:, :16] ** 2).sum(0), 1e-4, 1e-3)
+    assert torch.equal(slc, out[:, :16])
     # eval mode
     lib.call("stes_bn_finalize", None, None, 0.0, lib.ptr(dev(gamma)), lib.ptr(dev(beta)), lib.ptr(dev(rm)), lib.ptr(dev(rv)),
              0.1, 1e-5, 0, lib.ptr(scale), lib.ptr(shift), None, None, Cc)
@@ -133,7 +135,7 @@ def test_bn_finalize_and_act_residual():
     with torch.no_grad():
         bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
         ref = torch.relu(bn(c.float()))
-    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), None, None, None, lib.ptr(out), None, None, 0, M, Cc)
+    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), None, None, None, lib.ptr(out), None, None, 0, None, M, Cc)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
 
@@ -233,43 +235,56 @@ def test_block_in_grad_and_pool_bwd():
     close(out, ref, 1e-2, 1e-3)
 
 
-def _gsm_run(z, mode, dev_bf=True):
-    """Run the GSM kernels on a golden case; returns (y, grads...) in the reference's NCHW layout."""
+def _gsm_run(z, mode):
+    """Run the GSM kernels on a golden case; returns y and the gradients in the reference's NCHW layout and channel order
+    (the kernels keep source channel order; dest(c) is the reference's within-group interleave)."""
     from spot_amd import lib
     x = torch.from_numpy(z["x"]); gy = torch.from_numpy(z["gy"])
     NT, fold, H, W = x.shape
     T = int(z["T"]); B = NT // T
     M = NT * H * W
+    half, quarter = fold // 2, fold // 4
+    dest = [(c // half) * half + 2 * ((c % half) % quarter) + (c % half) // quarter for c in range(fold)]
     d = lambda a: dev(torch.from_numpy(np.asarray(a)))
-    X = dev(nhwc(x).to(BF))                      # ldx = fold
-    geom = lib.gsm_geom(B, T, H, W, fold, fold)
+    # a strided block input [M, fold + 24]: the compact slice copy and its statistics come from stes_col_stats
+    Xfull = torch.zeros(M, fold + 24, dtype=BF); Xfull[:, :fold] = nhwc(x).to(BF)
+    Xfull = dev(Xfull)
+    Xc = torch.empty(M, fold, dtype=BF, device="cuda")
+    geom = lib.gsm_geom(B, T, H, W, fold)
     s1 = torch.zeros(fold, device="cuda"); s2 = torch.zeros(fold, device="cuda")
-    lib.call("stes_col_stats", lib.ptr(X), fold, fold, M, lib.ptr(s1), lib.ptr(s2))
+    lib.call("stes_col_stats", lib.ptr(Xfull), fold + 24, fold, M, lib.ptr(s1), lib.ptr(s2), lib.ptr(Xc))
     scale, shift, mean, inv = (torch.empty(fold, device="cuda") for _ in range(4))
     rm, rv = d(z["rm0"]).clone(), d(z["rv0"]).clone()
-    lib.call("stes_bn_finalize", lib.ptr(s1), lib.ptr(s2), float(M), lib.ptr(d(z["bn_w"])), lib.ptr(d(z["bn_b"])), lib.ptr(rm), lib.ptr(rv),
+    gam = d(z["bn_w"])
+    lib.call("stes_bn_finalize", lib.ptr(s1), lib.ptr(s2), float(M), lib.ptr(gam), lib.ptr(d(z["bn_b"])), lib.ptr(rm), lib.ptr(rv),
              0.1, 1e-5, int(mode == "train"), lib.ptr(scale), lib.ptr(shift), lib.ptr(mean), lib.ptr(inv), fold)
     w3d, b3d = d(z["conv_w"]).contiguous(), d(z["conv_b"]).contiguous()
+    wt = torch.empty(27 * fold, device="cuda")
+    lib.call("stes_gsm_prep", lib.ptr(w3d), lib.ptr(wt), fold)
     gate = torch.empty(M, 2, device="cuda")
-    lib.call("stes_gsm_gate", lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(b3d), lib.ptr(gate), C.byref(geom))
+    lib.call("stes_gsm_gate", lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(wt), lib.ptr(b3d), lib.ptr(gate), C.byref(geom))
     G = torch.empty(M, fold, dtype=BF, device="cuda")
-    lib.call("stes_gsm_shift", lib.ptr(X), lib.ptr(gate), lib.ptr(G), C.byref(geom))
-    res = {"y": nchw(G.float().cpu(), NT, H, W), "rm": rm.cpu(), "rv": rv.cpu()}
+    lib.call("stes_gsm_shift", lib.ptr(Xc), lib.ptr(gate), lib.ptr(G), C.byref(geom))
+    y = torch.empty(NT, fold, H, W)
+    y[:, dest] = nchw(G.float().cpu(), NT, H, W)
+    res = {"y": y, "rm": rm.cpu(), "rv": rv.cpu()}
     if mode == "train":
-        dG = dev(nhwc(gy).to(BF))
+        dG = dev(nhwc(gy[:, dest]).to(BF))                       # gradient w.r.t. G in source order
         dpre = torch.empty(M, 2, device="cuda")
-        lib.call("stes_gsm_bwd_gate", lib.ptr(dG), fold, lib.ptr(X), lib.ptr(gate), lib.ptr(dpre), C.byref(geom))
+        lib.call("stes_gsm_bwd_gate", lib.ptr(dG), lib.ptr(Xc), lib.ptr(gate), lib.ptr(dpre), C.byref(geom))
         dw = torch.zeros_like(w3d); db = torch.zeros(2, device="cuda")
-        lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
+        lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
+        dxbn = torch.empty(M, fold, dtype=BF, device="cuda")
+        lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn), C.byref(geom))
         sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
-        lib.call("stes_gsm_bwd_bnreduce", lib.ptr(dpre), lib.ptr(X), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(sd), lib.ptr(sdx), C.byref(geom))
+        lib.bn_bwd_reduce(dxbn, Xc, M, fold, [sd, sdx])
         coef = [torch.empty(fold, device="cuda") for _ in range(3)]
         dgam = torch.zeros(fold, device="cuda"); dbet = torch.zeros(fold, device="cuda")
-        lib.call("stes_bn_bwd_finalize", lib.ptr(sd), lib.ptr(sdx), lib.ptr(mean), lib.ptr(inv), lib.ptr(d(z["bn_w"])), float(M),
+        lib.call("stes_bn_bwd_finalize", lib.ptr(sd), lib.ptr(sdx), lib.ptr(mean), lib.ptr(inv), lib.ptr(gam), float(M),
                  lib.ptr(coef[0]), lib.ptr(coef[1]), lib.ptr(coef[2]), lib.ptr(dgam), lib.ptr(dbet), fold)
         dXf = torch.empty(M, fold, dtype=BF, device="cuda")
-        lib.call("stes_gsm_bwd_dx", lib.ptr(dG), fold, lib.ptr(X), lib.ptr(gate), lib.ptr(dpre), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d),
-                 lib.ptr(coef[0]), lib.ptr(coef[1]), lib.ptr(coef[2]), lib.ptr(dXf), C.byref(geom))
+        lib.call("stes_gsm_bwd_dx", lib.ptr(dG), lib.ptr(Xc), lib.ptr(gate), lib.ptr(dxbn), lib.ptr(coef[0]), lib.ptr(coef[1]),
+                 lib.ptr(coef[2]), lib.ptr(dXf), C.byref(geom))
         res.update(gx=nchw(dXf.float().cpu(), NT, H, W), dw=dw.cpu(), db=db.cpu(), dgam=dgam.cpu(), dbet=dbet.cpu())
     torch.cuda.synchronize()
     return res
@@ -464,14 +479,22 @@ def test_cast_and_dropout():
     g = torch.Generator().manual_seed(4)
     w = torch.randn(7, 20, generator=g)
     a = torch.empty(8, 24, dtype=BF, device="cuda"); b = torch.empty(24, 8, dtype=BF, device="cuda")
-    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(a), 7, 20, 24, 8, 0)
-    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(b), 7, 20, 8, 24, 1)
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(a), 7, 20, 24, 8, 0, 0)
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(b), 7, 20, 8, 24, 1, 0)
+    # gated-shift column interleave folded into the cast: destination column c reads source column dest(c)
+    pa = torch.empty(8, 24, dtype=BF, device="cuda"); pb = torch.empty(24, 8, dtype=BF, device="cuda")
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(pa), 7, 20, 24, 8, 0, 8)
+    lib.call("stes_cast_bf16", lib.ptr(dev(w)), lib.ptr(pb), 7, 20, 8, 24, 1, 8)
     x = dev(bfr(4096, g=g)); out = torch.empty_like(x); mask = torch.empty_like(x)
     lib.call("stes_dropout", lib.ptr(x), lib.ptr(out), lib.ptr(mask), 4096, 0.5, 1234)
     torch.cuda.synchronize()
     ref = torch.zeros(8, 24); ref[:7, :20] = w.to(BF).float()
     assert torch.equal(a.float().cpu(), ref)
     assert torch.equal(b.float().cpu()[:20, :7], w.to(BF).float().t()) and float(b.float().cpu()[20:].abs().max()) == 0
+    dest8 = [0, 2, 1, 3, 4, 6, 5, 7]
+    wperm = w.clone(); wperm[:, :8] = w[:, dest8]
+    assert torch.equal(pa.float().cpu()[:7, :20], wperm.to(BF).float())
+    assert torch.equal(pb.float().cpu()[:20, :7], wperm.to(BF).float().t())
     mk = mask.float().cpu()
     assert set(mk.unique().tolist()) <= {0.0, 2.0} and 0.4 < float((mk > 0).float().mean()) < 0.6
     assert torch.equal(out.float().cpu(), (x.float().cpu() * mk).to(BF).float())
