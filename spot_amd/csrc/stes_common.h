@@ -48,3 +48,29 @@ int stes_set_error(int code, const char* msg);
     do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return stes_set_error(STES_ERR_LAUNCH, hipGetErrorString(e_)); } while (0)
 
 static inline int stes_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Division of a 32-bit index by a run-time constant without the ~30-instruction integer divide (row -> image / pixel
+// decoding sits in the inner loop of every NHWC kernel).  Granlund-Montgomery round-up form, exact for all 32-bit x.
+struct FastDiv {
+    uint32_t magic, shift, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.magic = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    f.shift = s;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, const FastDiv& f) {
+    if (f.d <= 1) return x;
+    const uint32_t t = __umulhi(x, f.magic);
+    return (t + ((x - t) >> 1)) >> (f.shift - 1);
+}
+__device__ __forceinline__ void fdivmod(uint32_t x, const FastDiv& f, uint32_t& q, uint32_t& r) {
+    q = fdiv(x, f);
+    r = x - q * f.d;
+}
+#define STES_MAX_ROWS 0x7fffffffL

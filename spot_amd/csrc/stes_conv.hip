@@ -34,10 +34,11 @@ __global__ void pack_conv3x3g_kernel(const float* __restrict__ w, bf16* __restri
 
 struct ConvGeom {
     int N, Hs, Ws, Hd, Wd, stride, C, G;
-    long Md;
+    uint32_t Md;
+    FastDiv fd_wd, fd_hd;
 };
 
-template <int MODE>   // 0 forward (dst = conv output), 1 dgrad (dst = conv input)
+template <int MODE, int STRIDE>   // MODE 0 forward (dst = conv output), 1 dgrad (dst = conv input)
 __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
                                                        bf16* __restrict__ dst, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* col_sum, float* col_sumsq,
@@ -59,17 +60,16 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
     }
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     const bool stats = (MODE == 0) && col_sum != nullptr;
-    const long hw_d = (long)gm.Hd * gm.Wd;
+    const int Hs = gm.Hs, Ws = gm.Ws;
 
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const long m = (long)t * 16 + p;
+        const uint32_t m = (uint32_t)t * 16 + p;
         const bool valid = m < gm.Md;
-        int n = 0, hd = 0, wd = 0;
-        if (valid) {
-            n = (int)(m / hw_d);
-            const int rem = (int)(m - (long)n * hw_d);
-            hd = rem / gm.Wd; wd = rem - hd * gm.Wd;
-        }
+        uint32_t row, wd_, n_, hd_;
+        fdivmod(valid ? m : 0u, gm.fd_wd, row, wd_);
+        fdivmod(row, gm.fd_hd, n_, hd_);
+        const int hd = (int)hd_, wd = (int)wd_;
+        const long nbase = (long)n_ * Hs * Ws;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
@@ -79,16 +79,16 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
                 const int kh = tap / 3, kw = tap - kh * 3;
                 int hs, ws; bool ok;
                 if (MODE == 0) {
-                    hs = hd * gm.stride + kh - 1; ws = wd * gm.stride + kw - 1;
-                    ok = hs >= 0 && hs < gm.Hs && ws >= 0 && ws < gm.Ws;
+                    hs = hd * STRIDE + kh - 1; ws = wd * STRIDE + kw - 1;
+                    ok = hs >= 0 && hs < Hs && ws >= 0 && ws < Ws;
                 } else {
                     const int th = hd + 1 - kh, tw = wd + 1 - kw;
-                    ok = th >= 0 && tw >= 0 && (th % gm.stride == 0) && (tw % gm.stride == 0);
-                    hs = th / gm.stride; ws = tw / gm.stride;
-                    ok = ok && hs < gm.Hs && ws < gm.Ws;
+                    ok = th >= 0 && tw >= 0 && (STRIDE == 1 || (((th | tw) & 1) == 0));
+                    hs = STRIDE == 1 ? th : th >> 1; ws = STRIDE == 1 ? tw : tw >> 1;
+                    ok = ok && hs < Hs && ws < Ws;
                 }
                 if (ok) {
-                    frag = *reinterpret_cast<const bf16x8*>(src + (((long)n * gm.Hs + hs) * gm.Ws + ws) * C + cin0);
+                    frag = *reinterpret_cast<const bf16x8*>(src + (nbase + (long)hs * Ws + ws) * C + cin0);
                     if (affine) {
                         float f[8];
                         unpack8(frag, f);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[r];
-            *reinterpret_cast<bf16x4*>(dst + m * C + g * 16 + q * 4) = o;
+            *reinterpret_cast<bf16x4*>(dst + (long)m * C + g * 16 + q * 4) = o;
             if (stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float v = (float)o[r]; ssum[r] += v; ssq[r] += v * v; }
@@ -131,9 +131,13 @@ __device__ __forceinline__ int rho32(int m) { return (m & ~12) | ((m & 4) << 1) 
 __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ dw, int N, int Hi, int Wi, int Ho, int Wo,
-                                                             int stride, int C, int n_items, int tiles_h, int tiles_w) {
-    __shared__ __attribute__((aligned(16))) bf16 Pt[4 * 32 * 16];
-    __shared__ __attribute__((aligned(16))) bf16 It[4 * MAX_HALO * 16];
+                                                             int stride, int C, int n_items, FastDiv fd_tiles, FastDiv fd_tw,
+                                                             FastDiv fd_iw) {
+    // one LDS block: staging tiles while walking items, then re-used to lay the result out for coalesced atomics
+    __shared__ __attribute__((aligned(16))) unsigned char smem[9216 * 4];
+    bf16* Pt = reinterpret_cast<bf16*>(smem);                     // [4 groups][32 px (rho)][16]
+    bf16* It = reinterpret_cast<bf16*>(smem + 4 * 32 * 16 * 2);    // [4 groups][MAX_HALO][16]
+    float* red = reinterpret_cast<float*>(smem);                  // [4 groups][16 co][16 ci][9]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int gq = blockIdx.y;
@@ -151,7 +155,6 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // fragment geometry (constant over items)
     const int px_lo = 8 * fq + (fr >> 2), px_hi = px_lo + 4;
     const int cc = 4 * (fr & 3);
     const int a_lo = (wave * 32 + rho32(px_lo)) * 16 + cc, a_hi = (wave * 32 + rho32(px_hi)) * 16 + cc;
@@ -159,9 +162,10 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
     const int hb_hi = ((px_hi >> 3) * stride) * IW + (px_hi & 7) * stride;
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int n = item / (tiles_h * tiles_w);
-        const int tr = item - n * tiles_h * tiles_w;
-        const int ho0 = (tr / tiles_w) * TH, wo0 = (tr % tiles_w) * TW;
+        uint32_t n, tr, trow, tcol;
+        fdivmod((uint32_t)item, fd_tiles, n, tr);
+        fdivmod(tr, fd_tw, trow, tcol);
+        const int ho0 = (int)trow * TH, wo0 = (int)tcol * TW;
         {   // dOut tile: thread -> pixel tid/8, chunk tid%8
             const int px = tid >> 3;
             const int ho = ho0 + (px >> 3), wo = wo0 + (px & 7);
@@ -170,8 +174,10 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
             *reinterpret_cast<bf16x8*>(&Pt[(cgrp * 32 + rho32(px)) * 16 + chalf * 8]) = v;
         }
         for (int i = tid; i < halo * 8; i += 256) {
-            const int hp = i >> 3;
-            const int hi = ho0 * stride - 1 + hp / IW, wi = wo0 * stride - 1 + hp % IW;
+            const uint32_t hp = (uint32_t)i >> 3;
+            uint32_t hr, hc;
+            fdivmod(hp, fd_iw, hr, hc);
+            const int hi = ho0 * stride - 1 + (int)hr, wi = wo0 * stride - 1 + (int)hc;
             bf16x8 v = zero8();
             if (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) {
                 v = *reinterpret_cast<const bf16x8*>(in + (((long)n * Hi + hi) * Wi + wi) * C + cbase);
@@ -201,14 +207,14 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
         }
         __syncthreads();
     }
-    const int g = gq * 4 + wave;
+    // result -> LDS in the checkpoint layout [co][ci][tap] of the 64 channels of this workgroup, then contiguous atomics
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = fq * 4 + r, ci = fr;
-            atomicAdd(dw + ((long)(g * 16 + co) * 16 + ci) * 9 + t, acc[t][r]);
-        }
+        for (int r = 0; r < 4; ++r) red[((wave * 16 + fq * 4 + r) * 16 + fr) * 9 + t] = acc[t][r];
+    __syncthreads();
+    float* dst = dw + (long)gq * 9216;
+    for (int i = tid; i < 9216; i += 256) atomicAdd(dst + i, red[i]);
 }
 
 // ------------------------------------------------------------------ stem im2col
@@ -267,18 +273,20 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     gm.N = N; gm.stride = stride; gm.C = C; gm.G = C / 16;
     if (mode == 0) { gm.Hs = Hi; gm.Ws = Wi; gm.Hd = Ho; gm.Wd = Wo; }
     else { gm.Hs = Ho; gm.Ws = Wo; gm.Hd = Hi; gm.Wd = Wi; }
-    gm.Md = (long)N * gm.Hd * gm.Wd;
-    const int n_tiles = stes_div_up(gm.Md, 16);
+    const long md = (long)N * gm.Hd * gm.Wd;
+    STES_CHECK(md <= STES_MAX_ROWS && (long)N * gm.Hs * gm.Ws <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_conv3x3g: more than 2^31 pixels");
+    gm.Md = (uint32_t)md;
+    gm.fd_wd = make_fastdiv(gm.Wd); gm.fd_hd = make_fastdiv(gm.Hd);
+    const int n_tiles = stes_div_up(md, 16);
     const int gy = gm.G / 4;
     int gx = n_tiles;
     const int cap = 4096 / gy > 1 ? 4096 / gy : 1;
     if (gx > cap) gx = cap;
-    if (mode == 0)
-        hipLaunchKernelGGL(conv3x3g_kernel<0>, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst, scale,
-                           shift, col_sum, col_sumsq, gm, n_tiles);
-    else
-        hipLaunchKernelGGL(conv3x3g_kernel<1>, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst, scale,
-                           shift, col_sum, col_sumsq, gm, n_tiles);
+#define CONV_LAUNCH(MODE, ST) hipLaunchKernelGGL((conv3x3g_kernel<MODE, ST>), dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)src, \
+        (const bf16*)wp, (bf16*)dst, scale, shift, col_sum, col_sumsq, gm, n_tiles)
+    if (mode == 0) { if (stride == 1) CONV_LAUNCH(0, 1); else CONV_LAUNCH(0, 2); }
+    else { if (stride == 1) CONV_LAUNCH(1, 1); else CONV_LAUNCH(1, 2); }
+#undef CONV_LAUNCH
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -305,8 +313,9 @@ extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, con
     int gx = n_items;
     const int cap = 2048 / gy > 1 ? 2048 / gy : 1;
     if (gx > cap) gx = cap;
+    const int IW = (TW - 1) * stride + 3;
     hipLaunchKernelGGL(conv3x3g_wgrad_kernel, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)dout, (const bf16*)in, in_scale, in_shift,
-                       dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, th, tw);
+                       dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, make_fastdiv(th * tw), make_fastdiv(tw), make_fastdiv(IW));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(TPB) void f32_outer_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------- BN backward
 struct DySrc {
-    const bf16* D; const float* mul; const float* add; int group;
+    const bf16* D; const float* mul; const float* add; FastDiv group;
     const bf16* act_raw; const float* act_scale; const float* act_shift;
 };
 
@@ -252,13 +252,13 @@ __device__ __forceinline__ void compute_dy(const DySrc& d, long m, int C, int c0
     load8b(d.D + m * C + c0, dy);
     if (d.mul) {
         float mu[8];
-        load8f(d.mul + (m / d.group) * C + c0, mu);
+        load8f(d.mul + (long)fdiv((uint32_t)m, d.group) * C + c0, mu);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dy[i] *= mu[i];
     }
     if (d.add) {
         float ad[8];
-        load8f(d.add + (m / d.group) * C + c0, ad);
+        load8f(d.add + (long)fdiv((uint32_t)m, d.group) * C + c0, ad);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dy[i] += ad[i];
     }
@@ -270,14 +270,14 @@ __device__ __forceinline__ void compute_dy(const DySrc& d, long m, int C, int c0
     }
 }
 
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_args p) {
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_args p, FastDiv fd_group) {
     extern __shared__ float lds[];     // [3][C]
     const int C = p.C, CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
     const long TT = (long)gridDim.x * TPB;
     const int c0 = (int)(gt % CH) * 8;
     const long rstep = TT / CH;
-    DySrc d{(const bf16*)p.D, p.mul, p.add, p.group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
+    DySrc d{(const bf16*)p.D, p.mul, p.add, fd_group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
     float as[8], ab[8];
     if (d.act_raw) { load8f(p.act_scale + c0, as); load8f(p.act_shift + c0, ab); }
     float s0[8], s1[8], s2[8];
@@ -329,13 +329,13 @@ __global__ void bn_bwd_finalize_kernel(const float* s_dy, const float* s_dyr, co
     if (dbeta) dbeta[c] += db;
 }
 
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const stes_bn_bwd_args p) {
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const stes_bn_bwd_args p, FastDiv fd_group) {
     const int C = p.C, CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
     const long TT = (long)gridDim.x * TPB;
     const int c0 = (int)(gt % CH) * 8;
     const long rstep = TT / CH;
-    DySrc d{(const bf16*)p.D, p.mul, p.add, p.group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
+    DySrc d{(const bf16*)p.D, p.mul, p.add, fd_group, (const bf16*)p.act_raw, p.act_scale, p.act_shift};
     float as[8], ab[8], al[8], be[8], de[8];
     if (d.act_raw) { load8f(p.act_scale + c0, as); load8f(p.act_shift + c0, ab); }
     load8f(p.alpha + c0, al); load8f(p.beta + c0, be); load8f(p.delta + c0, de);
@@ -356,21 +356,23 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const stes_bn_bwd_arg
 __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restrict__ dY, long ldy, const bf16* __restrict__ dXf,
                                                             int fold, const bf16* __restrict__ resid, int ms, int Ho, int Wo,
                                                             int Hi, int Wi, const bf16* __restrict__ X, bf16* __restrict__ out,
-                                                            long M, int C) {
+                                                            long M, int C, FastDiv fd_ch, FastDiv fd_hw, FastDiv fd_wi) {
     const int CH = C / 8;
-    const long total = M * CH;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long m = i / CH; const int c0 = (int)(i - m * CH) * 8;
+    const uint32_t total = (uint32_t)(M * CH);
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+        uint32_t m, chk;
+        fdivmod(i, fd_ch, m, chk);
+        const int c0 = (int)chk * 8;
         float v[8], x[8];
-        if (c0 < fold) load8b(dXf + m * fold + c0, v); else load8b(dY + m * ldy + c0, v);
+        if (c0 < fold) load8b(dXf + (long)m * fold + c0, v); else load8b(dY + (long)m * ldy + c0, v);
         if (resid) {
             long rm = m; bool ok = true;
             if (ms > 1) {
-                const long hw = (long)Hi * Wi;
-                const long n = m / hw; const int rem = (int)(m - n * hw);
-                const int hi = rem / Wi, wi = rem - hi * Wi;
-                ok = (hi % ms == 0) && (wi % ms == 0) && (hi / ms < Ho) && (wi / ms < Wo);
-                rm = (n * Ho + hi / ms) * Wo + wi / ms;
+                uint32_t n, rem, hi, wi;
+                fdivmod(m, fd_hw, n, rem);
+                fdivmod(rem, fd_wi, hi, wi);
+                ok = ((hi | wi) & 1) == 0 && (int)(hi >> 1) < Ho && (int)(wi >> 1) < Wo;      // ms == 2
+                rm = ((long)n * Ho + (hi >> 1)) * Wo + (wi >> 1);
             }
             if (ok) {
                 float r[8];
@@ -379,22 +381,24 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
         }
-        load8b(X + m * C + c0, x);
+        load8b(X + (long)m * C + c0, x);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = x[k] > 0.f ? v[k] : 0.f;
-        store8b(out + m * C + c0, v);
+        store8b(out + (long)m * C + c0, v);
     }
 }
 
 // dZ[m,c] = (da[n,c] + db[n,c]) * inv_hw * (out[m,c] > 0)
 __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__ da, const float* __restrict__ db,
                                                        const bf16* __restrict__ outp, bf16* __restrict__ dZ, int HW, int C,
-                                                       float inv_hw, long M) {
+                                                       float inv_hw, long M, FastDiv fd_ch, FastDiv fd_hw) {
     const int CH = C / 8;
-    const long total = M * CH;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long m = i / CH; const int c0 = (int)(i - m * CH) * 8;
-        const long n = m / HW;
+    const uint32_t total = (uint32_t)(M * CH);
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+        uint32_t m, chk;
+        fdivmod(i, fd_ch, m, chk);
+        const int c0 = (int)chk * 8;
+        const long n = fdiv(m, fd_hw);
         float g[8], o[8];
         load8f(da + n * C + c0, g);
         if (db) {
@@ -403,10 +407,10 @@ __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] += h[k];
         }
-        load8b(outp + m * C + c0, o);
+        load8b(outp + (long)m * C + c0, o);
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] * inv_hw : 0.f;
-        store8b(dZ + m * C + c0, g);
+        store8b(dZ + (long)m * C + c0, g);
     }
 }
 
@@ -479,6 +483,7 @@ extern "C" int stes_f32_outer(const float* P, const float* Q, float* dW, float* 
 
 static int check_bwd(const stes_bn_bwd_args* a, const char* who) {
     STES_CHECK(a && a->D && a->raw1 && a->M > 0, STES_ERR_ARG, who);
+    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "bn_bwd: more than 2^31 rows");
     STES_CHECK(a->C % 8 == 0, STES_ERR_ARG, "bn_bwd: C must be a multiple of 8");
     STES_CHECK((!a->mul && !a->add) || a->group > 0, STES_ERR_ARG, "bn_bwd: group");
     STES_CHECK(!a->act_raw || (a->act_scale && a->act_shift), STES_ERR_ARG, "bn_bwd: mask affine");
@@ -490,7 +495,7 @@ extern "C" int stes_bn_bwd_reduce(const stes_bn_bwd_args* a, void* stream) {
     if (rc) return rc;
     STES_CHECK(a->s_dy && a->s_dyr1 && (!a->raw2 || a->s_dyr2), STES_ERR_ARG, "stes_bn_bwd_reduce: outputs");
     const int grid = flat_grid(a->M, a->C / 8, 1024);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(TPB), 3 * a->C * sizeof(float), S(stream), *a);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(TPB), 3 * a->C * sizeof(float), S(stream), *a, make_fastdiv(a->group > 0 ? a->group : 1));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -510,7 +515,7 @@ extern "C" int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream) {
     if (rc) return rc;
     STES_CHECK(a->alpha && a->beta && a->delta && a->out, STES_ERR_ARG, "stes_bn_bwd_apply: coefficients/output");
     const int grid = flat_grid(a->M, a->C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(TPB), 0, S(stream), *a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(TPB), 0, S(stream), *a, make_fastdiv(a->group > 0 ? a->group : 1));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -520,10 +525,13 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
                                   int64_t M, int C, void* stream) {
     STES_CHECK(dY && X && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
     STES_CHECK(C % 8 == 0 && fold % 8 == 0 && ldy % 8 == 0 && (fold == 0 || dXf), STES_ERR_ARG, "stes_block_in_grad: alignment");
+    STES_CHECK(map_stride == 1 || map_stride == 2, STES_ERR_UNSUPPORTED, "stes_block_in_grad: stride must be 1 or 2");
+    STES_CHECK(M * (C / 8) <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
     long blocks = (M * (C / 8) + TPB - 1) / TPB;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(block_in_grad_kernel, dim3((int)blocks), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf, fold,
-                       (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C);
+                       (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, make_fastdiv(C / 8),
+                       make_fastdiv(Hi * Wi), make_fastdiv(Wi));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -534,8 +542,9 @@ extern "C" int stes_pool_bwd(const float* da, const float* db, const uint16_t* o
     const long M = (long)N * HW;
     long blocks = (M * (C / 8) + TPB - 1) / TPB;
     if (blocks > 4096) blocks = 4096;
+    STES_CHECK(M * (C / 8) <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_pool_bwd: tensor too large");
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, S(stream), da, db, (const bf16*)out, (bf16*)dZ, HW, C,
-                       1.0f / HW, M);
+                       1.0f / HW, M, make_fastdiv(C / 8), make_fastdiv(HW));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

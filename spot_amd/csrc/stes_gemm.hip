@@ -30,8 +30,10 @@ struct RowInfo {
     const float* gate;   // gate row pointer
 };
 
+struct RowDivs { FastDiv hw, wo, gate; };
+
 template <int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots) {
+__global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv) {
     constexpr int NI = BN / 32;          // 16-wide n fragments per wave (wave covers BN/2 columns)
     constexpr int BLOADS = BN / 64;      // W-tile chunk loads per thread
     __shared__ __attribute__((aligned(16))) bf16 As[2][BM * BK];
@@ -78,14 +80,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
             if (m < M) {
                 long src = m;
                 if (p.map_stride > 1) {
-                    const long hw = (long)p.Ho * p.Wo;
-                    const long n = m / hw; const int rem = (int)(m - n * hw);
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    src = (n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                    uint32_t n, rem, ho, wo;
+                    fdivmod((uint32_t)m, dv.hw, n, rem);
+                    fdivmod(rem, dv.wo, ho, wo);
+                    src = ((long)n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
                 }
                 ri[h].a = A + src * p.lda;
                 if (A0) ri[h].a0 = A0 + src * p.lda0;
-                if (has_gate) ri[h].gate = p.a_gate + (m / p.gate_group) * (long)K;
+                if (has_gate) ri[h].gate = p.a_gate + (long)fdiv((uint32_t)m, dv.gate) * K;
             }
         }
         const bf16* wrow[BLOADS];
@@ -261,7 +263,7 @@ __device__ __forceinline__ int gsm_dest(int c, int fold) {
 }
 
 template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
-__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, RowDivs dv) {
     constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
     constexpr int FI = T / 32;               // 16-wide fragments per wave per operand
     constexpr int CH = T / 8;                // 16-byte chunks per tile row
@@ -310,10 +312,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
                 rp[h] = c1_ok ? *reinterpret_cast<const bf16x8*>(P + m * p.ldp + c1) : zero8();
                 long src = m;
                 if (p.map_stride > 1) {
-                    const long hw = (long)p.Ho * p.Wo;
-                    const long n = m / hw; const int rem = (int)(m - n * hw);
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    src = (n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                    uint32_t n, rem, ho, wo;
+                    fdivmod((uint32_t)m, dv.hw, n, rem);
+                    fdivmod(rem, dv.wo, ho, wo);
+                    src = ((long)n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
                 }
                 if (c2_ok) rq[h] = (c2 < p.k0) ? *reinterpret_cast<const bf16x8*>(Q0 + src * p.ldq0 + c2)
                                                : *reinterpret_cast<const bf16x8*>(Q + src * p.ldq + c2);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
                     }
                 }
                 if (has_gate) {
-                    const float* g = p.q_gate + (qm[h] / p.gate_group) * (long)p.N2 + c2;
+                    const float* g = p.q_gate + (long)fdiv((uint32_t)qm[h], dv.gate) * p.N2 + c2;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] *= g[i];
                 }
@@ -436,8 +438,13 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     if (m_slots > cap) m_slots = cap;
     const int slot_groups = stes_div_up(m_slots, 8);
     const int grid = slot_groups * n_tiles * 8;
-    if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots);
-    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots);
+    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_gemm: more than 2^31 rows");
+    RowDivs dv;
+    dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
+    dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
+    dv.gate = make_fastdiv(a->a_gate ? a->gate_group : 1);
+    if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
+    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -459,8 +466,13 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     if (chunk < 256) chunk = 256;
     chunk = (chunk + WK - 1) / WK * WK;
     const int mb = stes_div_up(a->M, chunk);
-    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk);
-    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk);
+    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_wgrad: more than 2^31 rows");
+    RowDivs dv;
+    dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
+    dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
+    dv.gate = make_fastdiv(a->q_gate ? a->gate_group : 1);
+    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, dv);
+    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, dv);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

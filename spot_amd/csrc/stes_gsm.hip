@@ -19,7 +19,13 @@ namespace {
 struct Geom {
     int B, T, H, W, fold;
     long M;
+    FastDiv fd_plane, fd_T, fd_W, fd_H, fd_nch;     // H*W, T, W, H, vector chunks per row
 };
+// frame index t of row m
+__device__ __forceinline__ int frame_of(uint32_t m, const Geom& gm) {
+    const uint32_t f = fdiv(m, gm.fd_plane);
+    return (int)(f - fdiv(f, gm.fd_T) * gm.T);
+}
 
 __device__ __forceinline__ int dest_of(int c, int fold) {
     const int half = fold >> 1, quarter = fold >> 2;
@@ -105,11 +111,13 @@ __global__ __launch_bounds__(256) void gsm_shift_kernel(const bf16* __restrict__
     typedef __bf16 vecb __attribute__((ext_vector_type(V)));
     const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
-    const long total = gm.M * nch;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long m = i / nch; const int c0 = (int)(i - m * nch) * V;
+    const uint32_t total = (uint32_t)(gm.M * nch);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint32_t mu, chk;
+        fdivmod(i, gm.fd_nch, mu, chk);
+        const long m = mu; const int c0 = (int)chk * V;
         const int g = c0 >= half;
-        const int t = (int)((m / plane) % gm.T);
+        const int t = frame_of(mu, gm);
         const vecb x = *reinterpret_cast<const vecb*>(Xc + m * fold + c0);
         const float gt = gate[m * 2 + g];
         const int tn = g == 0 ? t + 1 : t - 1;
@@ -139,10 +147,10 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restric
     typedef __bf16 vecb __attribute__((ext_vector_type(V)));
     const int fold = gm.fold, half = fold >> 1;
     const long plane = (long)gm.H * gm.W;
-    const long total = gm.M * 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const uint32_t total = (uint32_t)(gm.M * 2);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const long m = i >> 1; const int g = (int)(i & 1);
-        const int t = (int)((m / plane) % gm.T);
+        const int t = frame_of(i >> 1, gm);
         const int tp = g == 0 ? t - 1 : t + 1;                 // frame whose output used y[t]
         const bool has = tp >= 0 && tp < gm.T;
         const long mp = g == 0 ? m - plane : m + plane;
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restr
     constexpr int LDX = CP + 16;
     __shared__ __attribute__((aligned(16))) bf16 Dm[4][32 * 48];   // per wave: [32 pos (rho)][32 taps + 16 pad]
     __shared__ __attribute__((aligned(16))) bf16 Xb[4][32 * LDX];  // per wave: [32 pos (rho)][CP + 16 pad]
+    static_assert(sizeof(bf16) * 4 * 32 * LDX >= sizeof(float) * CP * 27, "result staging must fit the operand buffer");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int grp = blockIdx.y;
@@ -205,9 +214,10 @@ __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) vals[k] = (bf16)0.f;
             if (m < gm.M) {
-                const int w_ = (int)(m % W); long r = m / W;
-                const int h_ = (int)(r % H); r /= H;
-                const int t_ = (int)(r % T);
+                uint32_t r1, w_u, r2, h_u;
+                fdivmod((uint32_t)m, gm.fd_W, r1, w_u);
+                fdivmod(r1, gm.fd_H, r2, h_u);
+                const int w_ = (int)w_u, h_ = (int)h_u, t_ = (int)(r2 - fdiv(r2, gm.fd_T) * T);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int tap = th * 16 + k;
@@ -268,7 +278,11 @@ __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restr
             for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
     }
-    // D[row = tap (fq*4 + r)][col = channel (fr)]
+    // reduce the four waves in LDS, laid out as the checkpoint tensor [c][27] of this group, then contiguous atomics
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&Xb[0][0]);              // >= half*27 floats (CP*27*4 <= sizeof(Xb))
+    for (int i = threadIdx.x; i < half * 27; i += 256) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -276,8 +290,11 @@ __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tap = i * 16 + fq * 4 + r, c = j * 16 + fr;
-                if (tap < 27 && c < half) atomicAdd(dw + ((long)(grp * half + c)) * 27 + tap, acc[i][j][r]);
+                if (tap < 27 && c < half) atomicAdd(&red[c * 27 + tap], acc[i][j][r]);
             }
+    __syncthreads();
+    float* dst = dw + (long)grp * half * 27;
+    for (int i = threadIdx.x; i < half * 27; i += 256) atomicAdd(dst + i, red[i]);
     bsum = wave_sum(bsum);
     if (lane == 0) atomicAdd(db + grp, bsum);
 }
@@ -355,11 +372,13 @@ __global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict_
     typedef __bf16 vecb __attribute__((ext_vector_type(V)));
     const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
-    const long total = gm.M * nch;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long m = i / nch; const int c0 = (int)(i - m * nch) * V;
+    const uint32_t total = (uint32_t)(gm.M * nch);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint32_t mu, chk;
+        fdivmod(i, gm.fd_nch, mu, chk);
+        const long m = mu; const int c0 = (int)chk * V;
         const int g = c0 >= half;
-        const int t = (int)((m / plane) % gm.T);
+        const int t = frame_of(mu, gm);
         const int tp = g == 0 ? t - 1 : t + 1;
         const bool has = tp >= 0 && tp < gm.T;
         const long mp = g == 0 ? m - plane : m + plane;
@@ -433,6 +452,7 @@ int check_geom(const stes_gsm_geom* g) {
     STES_CHECK(g && g->B > 0 && g->T > 0 && g->H > 0 && g->W > 0, STES_ERR_ARG, "gsm: bad geometry");
     STES_CHECK(g->fold == 8 || (g->fold >= 16 && g->fold % 16 == 0), STES_ERR_ARG, "gsm: fold must be 8 or a multiple of 16");
     STES_CHECK(g->fold <= 192, STES_ERR_ARG, "gsm: fold > 192 is not built");
+    STES_CHECK((long)g->B * g->T * g->H * g->W * (g->fold / 4) <= 0xffffffffL, STES_ERR_UNSUPPORTED, "gsm: tensor too large");
     return STES_OK;
 }
 
@@ -440,6 +460,8 @@ Geom to_geom(const stes_gsm_geom* g) {
     Geom gm;
     gm.B = g->B; gm.T = g->T; gm.H = g->H; gm.W = g->W; gm.fold = g->fold;
     gm.M = (long)g->B * g->T * g->H * g->W;
+    gm.fd_plane = make_fastdiv(g->H * g->W); gm.fd_T = make_fastdiv(g->T); gm.fd_W = make_fastdiv(g->W); gm.fd_H = make_fastdiv(g->H);
+    gm.fd_nch = make_fastdiv(g->fold == 8 ? 2 : g->fold / 8);
     return gm;
 }
 
@@ -511,7 +533,7 @@ extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const f
     const Geom gm = to_geom(g);
     const int half = gm.fold / 2;
     const long n_chunks = (gm.M + 31) / 32;
-    long gx = (n_chunks + 3) / 4; if (gx > 1024) gx = 1024;
+    long gx = (n_chunks + 31) / 32; if (gx > 1024) gx = 1024;       // >= 8 chunks of 32 rows per wave
     const dim3 grid((int)gx, 2);
     const int nct = (half + 15) / 16;
 #define LAUNCH_WG(N) hipLaunchKernelGGL(gsm_bwd_wgrad_kernel<N>, grid, dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks)
