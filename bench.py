@@ -135,9 +135,8 @@ def main():
         from spot_amd import roofline
         rec["step_roofline"] = roofline.step_fractions(frames / dt)
         if not args.no_roofline:
-            rec["roofline"] = roofline.measure_dominant_kernel(model, x)
+            rec["roofline"] = roofline.measure_dominant_kernel(trainer, (x, label, xy))
         if not args.no_cpu_baseline:
-            del trainer
             rec["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(rec), flush=True)

@@ -199,10 +199,11 @@ typedef struct {
 } stes_gru_args;
 int stes_gru_forward(const stes_gru_args* a, void* stream);
 int stes_gru_backward(const stes_gru_args* a, void* stream);
-/* MinGRU recurrence, reference model/min_gru.py:76-92; pre = [gate pre-activation | candidate]. */
-int stes_mingru_scan_fwd(const uint16_t* pre, uint16_t* h, int B, int T, int H, void* stream);
-int stes_mingru_scan_bwd(const uint16_t* pre, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre, int B, int T,
-                         int H, void* stream);
+/* MinGRU recurrence, reference model/min_gru.py:76-92; pre = [gate pre-activation | candidate]; h0 [H] is the layer's
+ * frozen initial-state parameter (:42,60; NULL = zeros). */
+int stes_mingru_scan_fwd(const uint16_t* pre, const float* h0, uint16_t* h, int B, int T, int H, void* stream);
+int stes_mingru_scan_bwd(const uint16_t* pre, const float* h0, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre,
+                         int B, int T, int H, void* stream);
 /* nn.Dropout of GRUPrediction (model/modules.py:32): out = x*mask, mask in {0, 1/(1-p)} from a counter hash. */
 int stes_dropout(const uint16_t* x, uint16_t* out, uint16_t* mask, int64_t n, float p, uint32_t seed, void* stream);
 /* Weighted-mean cross entropy + masked L1 on sigmoid(loc) (train_e2e_spatial.py:566-593) and their

@@ -131,12 +131,14 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const stes_gru_args p
 }
 
 // ------------------------------------------------------------------ minGRU scan (reference model/min_gru.py:76-92)
-// pre [B,T,2H] bf16: columns [0,H) gate pre-activation, [H,2H) candidate; h_t = (1-z) h_{t-1} + z * cand, h_0 = 0
-__global__ void mingru_scan_fwd_kernel(const bf16* __restrict__ pre, bf16* __restrict__ h, int B, int T, int H) {
+// pre [B,T,2H] bf16: columns [0,H) gate pre-activation, [H,2H) candidate; h_t = (1-z) h_{t-1} + z * cand; the initial
+// state h0 [H] is the reference's frozen per-layer parameter (model/min_gru.py:42,60), zeros unless a checkpoint says otherwise
+__global__ void mingru_scan_fwd_kernel(const bf16* __restrict__ pre, const float* __restrict__ h0, bf16* __restrict__ h, int B, int T,
+                                       int H) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, j = i - b * H;
-    float hp = 0.f;
+    float hp = h0 ? h0[j] : 0.f;
     for (int t = 0; t < T; ++t) {
         const bf16* r = pre + ((long)b * T + t) * 2 * H;
         const float z = sigmoidf_((float)r[j]);
@@ -145,8 +147,8 @@ __global__ void mingru_scan_fwd_kernel(const bf16* __restrict__ pre, bf16* __res
     }
 }
 // dpre [B,T,2H] bf16 from dh [B,T,ld] f32; hidden states re-read from h (bf16)
-__global__ void mingru_scan_bwd_kernel(const bf16* __restrict__ pre, const bf16* __restrict__ h, const float* __restrict__ dh, long ld_dh,
-                                       bf16* __restrict__ dpre, int B, int T, int H) {
+__global__ void mingru_scan_bwd_kernel(const bf16* __restrict__ pre, const float* __restrict__ h0, const bf16* __restrict__ h,
+                                       const float* __restrict__ dh, long ld_dh, bf16* __restrict__ dpre, int B, int T, int H) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, j = i - b * H;
@@ -154,7 +156,7 @@ __global__ void mingru_scan_bwd_kernel(const bf16* __restrict__ pre, const bf16*
     for (int t = T - 1; t >= 0; --t) {
         const bf16* r = pre + ((long)b * T + t) * 2 * H;
         const float z = sigmoidf_((float)r[j]), cand = (float)r[H + j];
-        const float hp = t > 0 ? (float)h[((long)b * T + t - 1) * H + j] : 0.f;
+        const float hp = t > 0 ? (float)h[((long)b * T + t - 1) * H + j] : (h0 ? h0[j] : 0.f);
         const float g = dh[((long)b * T + t) * ld_dh + j] + carry;
         bf16* o = dpre + ((long)b * T + t) * 2 * H;
         o[j] = (bf16)(g * (cand - hp) * z * (1.f - z));
@@ -320,17 +322,17 @@ extern "C" int stes_gru_backward(const stes_gru_args* a, void* stream) {
     return STES_OK;
 }
 
-extern "C" int stes_mingru_scan_fwd(const uint16_t* pre, uint16_t* h, int B, int T, int H, void* stream) {
+extern "C" int stes_mingru_scan_fwd(const uint16_t* pre, const float* h0, uint16_t* h, int B, int T, int H, void* stream) {
     STES_CHECK(pre && h && B > 0 && T > 0 && H > 0, STES_ERR_ARG, "stes_mingru_scan_fwd: bad argument");
-    hipLaunchKernelGGL(mingru_scan_fwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, (bf16*)h, B, T, H);
+    hipLaunchKernelGGL(mingru_scan_fwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, h0, (bf16*)h, B, T, H);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_mingru_scan_bwd(const uint16_t* pre, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre, int B, int T,
-                                    int H, void* stream) {
+extern "C" int stes_mingru_scan_bwd(const uint16_t* pre, const float* h0, const uint16_t* h, const float* dh, int64_t ld_dh, uint16_t* dpre,
+                                    int B, int T, int H, void* stream) {
     STES_CHECK(pre && h && dh && dpre && ld_dh >= H, STES_ERR_ARG, "stes_mingru_scan_bwd: bad argument");
-    hipLaunchKernelGGL(mingru_scan_bwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, (const bf16*)h,
+    hipLaunchKernelGGL(mingru_scan_bwd_kernel, dim3(stes_div_up((long)B * H, 128)), dim3(128), 0, S(stream), (const bf16*)pre, h0, (const bf16*)h,
                        dh, (long)ld_dh, (bf16*)dpre, B, T, H);
     STES_LAUNCH_CHECK();
     return STES_OK;

@@ -602,7 +602,7 @@ class Engine:
                 Hh = lz.N
                 lib.gemm(xin, lz.w_bf, self.min_pre[i], N, Hh, in_dim, bias=lz.b, ldc=2 * Hh)
                 lib.gemm(xin, lh.w_bf, self.min_pre[i][Hh:], N, Hh, in_dim, bias=lh.b, ldc=2 * Hh)
-                lib.call("stes_mingru_scan_fwd", p(self.min_pre[i]), p(self.min_h[i]), B, T, Hh)
+                lib.call("stes_mingru_scan_fwd", p(self.min_pre[i]), p(self.impl._pred_fine.h0[i]), p(self.min_h[i]), B, T, Hh)
                 xin, in_dim = self.min_h[i], Hh
             self.fc_in = xin
             lib.gemm(xin, self.fc.w_bf, self.logits, N, self.fc.N, in_dim, bias=self.fc.b)

@@ -1,0 +1,59 @@
+"""Long-video sliding-window inference (the reference's inference_on_mp4.py path, :204-277) on pre-decoded frames.
+
+Video decoding (cv2) and rendering are outside the hot path; the input here is a float tensor [n_frames, 3, H, W] already
+resized and normalised (what the reference's v2.Resize/ToDtype/Normalize pipeline yields, inference_on_mp4.py:520-526).
+Windows have size = stride = clip_len (:531-532); the last window is zero-padded; windows are independent (the gated
+shift never crosses a clip, the GRU restarts per clip), so with N GPUs rank r takes every N-th batch of windows and the
+per-frame scores are gathered on the host: replicas only, no collective on the data path.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .util.postproc import ScoreAccumulator, events_from_scores, filter_events_by_score, non_max_suppression_events
+
+DEFAULT_CLASSES = ["serve", "receive", "set", "attack", "block", "score", "ball_hit_ground", "net_touch", "out"]
+
+
+def num_windows(n_frames, window, stride):
+    """reference inference_on_mp4.py:174"""
+    return max(1, math.ceil((n_frames - window) / stride + 1))
+
+
+def window_batches(n_frames, clip_len, batch_size, rank=0, world=1):
+    """Start frames of the windows this rank evaluates, grouped in batches (batch b goes to rank b % world)."""
+    starts = [i * clip_len for i in range(num_windows(n_frames, clip_len, clip_len))]
+    batches = [starts[i:i + batch_size] for i in range(0, len(starts), batch_size)]
+    return [b for i, b in enumerate(batches) if i % world == rank]
+
+
+def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=True, rank=0, world=1, video="video",
+                  gather=None):
+    """model: E2EModel; frames [n_frames, C, H, W] float tensor (host or device).  Returns the reference's
+    [{'video', 'events'}] list (after score filter 0.15 and NMS 3 when postprocess)."""
+    n_frames = frames.shape[0]
+    acc = ScoreAccumulator(n_frames, len(classes) + 1)
+    for starts in window_batches(n_frames, clip_len, batch_size, rank, world):
+        clips = []
+        for s in starts:
+            clip = frames[s:s + clip_len]
+            if clip.shape[0] < clip_len:       # zero-pad the last window
+                pad = torch.zeros((clip_len - clip.shape[0],) + tuple(clip.shape[1:]), dtype=clip.dtype, device=clip.device)
+                clip = torch.cat([clip, pad], 0)
+            clips.append(clip)
+        batch = torch.stack(clips, 0)
+        out = model.predict(batch)
+        scores, loc = out[1], (out[2] if len(out) > 2 else None)
+        for i, s in enumerate(starts):
+            acc.add(s, scores[i], None if loc is None else loc[i])
+    if gather is not None:                      # multi-rank: disjoint frame ranges, sum on the host
+        acc.scores, acc.support, acc.locations = gather(acc.scores, acc.support, acc.locations)
+    scores, locations = acc.finish()
+    pred_events = [{"video": video, "events": events_from_scores(scores, locations, classes)}]
+    if postprocess:
+        pred_events = filter_events_by_score(pred_events, fg_threshold=0.15)
+        pred_events = non_max_suppression_events(pred_events, 3)
+    return pred_events, scores

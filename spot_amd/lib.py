@@ -93,8 +93,8 @@ _SIGS = {
     "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gru_forward": [_P, _P],
     "stes_gru_backward": [_P, _P],
-    "stes_mingru_scan_fwd": [_P, _P, _I32, _I32, _I32, _P],
-    "stes_mingru_scan_bwd": [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
+    "stes_mingru_scan_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_mingru_scan_bwd": [_P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
     "stes_dropout": [_P, _P, _P, _I64, _F32, _U32, _P],
     "stes_loss": [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _F32, _F32, _P, _P, _P, _P, _P],
     "stes_adamw": [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _F32, _P],
@@ -138,6 +138,21 @@ def call(name, *args):
     check(getattr(lib(), name)(*args, stream()), name)
 
 
+# ---------------------------------------------------------------- optional per-launch timing (bench.py roofline leg)
+# When TIMING is a list, every stes_gemm launch that runs the 128-wide tile kernel is bracketed by HIP events recorded
+# on the launch stream and appended as (start, end, algorithmic_bytes, flops).
+TIMING = None
+
+
+def _gemm_work(a, out_bytes):
+    m, n, k = a.M, a.N, a.K
+    rows_in = m if not a.a_gate else m
+    byt = rows_in * k * 2 + n * k * 2 + m * n * out_bytes
+    if a.a_gate:
+        byt += (m // max(a.gate_group, 1)) * k * 4
+    return byt, 2 * m * n * k
+
+
 # ---------------------------------------------------------------- struct-argument entry points
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
@@ -158,6 +173,13 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
     a.C0, a.ldc0, a.n_split = ptr(C0), ldc0, n_split
     a.M, a.N, a.K = M, N, K
+    if TIMING is not None and N > 64:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
+        e1.record()
+        TIMING.append((e0, e1) + _gemm_work(a, 4 if a.c_f32 else 2))
+        return
     check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
 
 

@@ -49,5 +49,27 @@ def step_fractions(fps_per_gpu):
             "hbm_frac": w["step_bytes"] * fps_per_gpu / HBM_PEAK_BPS}
 
 
-def measure_dominant_kernel(model, x, reps=20):
-    return None
+def measure_dominant_kernel(trainer, batch, steps=3):
+    """Roofline of the kernel with the largest share of the step (gemm_kernel<128>: the 1x1 convolutions, their input
+    gradients and the head GEMMs, ~64 launches per step of different shapes).  Every launch of `steps` training steps is
+    bracketed by HIP events on the launch stream; achieved = sum of the launches' algorithmic bytes (A read once, W read
+    once, C written once, SE gate read once) / sum of their durations.  FLOP rate reported beside it."""
+    from . import lib
+    x, label, xy = batch
+    lib.TIMING = []
+    try:
+        for _ in range(steps):
+            trainer.step(x, label, xy)
+        torch.cuda.synchronize()
+        recs = lib.TIMING
+    finally:
+        lib.TIMING = None
+    t = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs) * 1e-3
+    byt = sum(r[2] for r in recs)
+    fl = sum(r[3] for r in recs)
+    n = len(recs)
+    gbs = byt / t / 1e9
+    return {"kernel": "gemm_kernel<128> (stes_gemm, 128-wide tile)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_BPS / 1e9,
+            "unit": "GB/s", "frac": gbs / (HBM_PEAK_BPS / 1e9), "traffic": None,
+            "launches_per_step": n // steps, "avg_launch_us": 1e6 * t / n, "algorithmic_bytes_per_launch": byt / n,
+            "tflops": fl / t / 1e12, "mfma_frac": fl / t / MFMA_PEAK_FLOPS}

@@ -426,7 +426,8 @@ def test_mingru_scan():
     pre = bfr(B, T, 2 * H, g=g)
     pr = pre.float().requires_grad_(True)
     z = torch.sigmoid(pr[..., :H]); cand = pr[..., H:]
-    h = torch.zeros(B, H); hs = []
+    h0 = torch.randn(H, generator=g) * 0.3
+    h = h0.expand(B, H); hs = []
     for t in range(T):
         h = (1 - z[:, t]) * h + z[:, t] * cand[:, t]
         hs.append(h)
@@ -434,12 +435,13 @@ def test_mingru_scan():
     dh = torch.randn(B, T, H, generator=g)
     hs.backward(dh)
     hd = torch.empty(B, T, H, dtype=BF, device="cuda")
-    lib.call("stes_mingru_scan_fwd", lib.ptr(dev(pre)), lib.ptr(hd), B, T, H)
+    h0d = dev(h0)
+    lib.call("stes_mingru_scan_fwd", lib.ptr(dev(pre)), lib.ptr(h0d), lib.ptr(hd), B, T, H)
     dpre = torch.empty(B, T, 2 * H, dtype=BF, device="cuda")
-    lib.call("stes_mingru_scan_bwd", lib.ptr(dev(pre)), lib.ptr(hd), lib.ptr(dev(dh)), H, lib.ptr(dpre), B, T, H)
+    lib.call("stes_mingru_scan_bwd", lib.ptr(dev(pre)), lib.ptr(h0d), lib.ptr(hd), lib.ptr(dev(dh)), H, lib.ptr(dpre), B, T, H)
     torch.cuda.synchronize()
-    close(hd, hs.detach(), 1e-2, 1e-2)
-    close(dpre, pr.grad, 3e-2, 2e-2)
+    close(hd, hs.detach(), 8e-3, 2e-3)
+    close(dpre, pr.grad, 2e-2, 5e-3)
 
 
 def test_loss_and_adamw_vs_reference_golden(golden):

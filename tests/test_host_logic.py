@@ -1,0 +1,133 @@
+"""CPU tests: host-side logic, the C-ABI surface, the data-parallel bucketing over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from spot_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from spot_amd.build import build
+        build(verbose=False)
+    dll = ctypes.CDLL(L.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "stes.h")).read()
+    declared = set(re.findall(r"\b(stes_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(dll, name), f"{name} declared in include/stes.h but not exported"
+    assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
+    dll.stes_version.restype = ctypes.c_int
+    assert dll.stes_version() >= 1
+
+
+def test_no_product_import_of_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "spot_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_engine_refuses_cpu():
+    from spot_amd.e2e import E2EModel
+    from spot_amd.lib import StesError
+    m = E2EModel(7, "rny008_gsm", "gru", clip_len=4, modality="rgb", device="cpu", predict_location=True, verbose=False)
+    with pytest.raises(StesError):
+        m.predict(torch.zeros(1, 4, 3, 32, 32))
+
+
+def test_unsupported_archs_raise_like_reference():
+    from spot_amd.e2e import E2EModel
+    with pytest.raises(NotImplementedError):
+        E2EModel(7, "rn18_gsm", "gru", clip_len=4, modality="rgb", device="cpu", verbose=False)
+    with pytest.raises(NotImplementedError):
+        E2EModel(7, "rny008_gsm", "lstm", clip_len=4, modality="rgb", device="cpu", verbose=False)
+    with pytest.raises(NotImplementedError):
+        E2EModel(7, "rny008_gsm", "gru", clip_len=4, modality="rgb", device="cpu", predict_location=True, pred_loc_arch="conv", verbose=False)
+
+
+def test_postproc_bit_exact_vs_reference_golden(golden):
+    from spot_amd.util import postproc as P
+    z = golden("postproc")
+    classes = ["serve", "receive", "set", "attack", "block", "score"]
+    ev = P.events_from_scores(z["scores"].copy(), z["locs"], classes)
+    f = P.filter_events_by_score([{"video": "v", "events": ev}], 0.15)
+    import copy
+    s = P.non_max_suppression_events(copy.deepcopy(f), 3)
+    lab = {c: i for i, c in enumerate(classes)}
+    enc = lambda e: np.array([[x["frame"], lab[x["label"]]] for x in e], np.int64).reshape(-1, 2)
+    assert np.array_equal(enc(f[0]["events"]), z["filtered"])
+    assert np.array_equal(enc(s[0]["events"]), z["nms"])
+    assert np.array_equal(np.array([e["score"] for e in s[0]["events"]]), z["nms_scores"])
+
+
+def test_sliding_window_accumulator_and_sharding():
+    from spot_amd import infer
+    from spot_amd.util.postproc import ScoreAccumulator
+    assert infer.num_windows(15000, 64, 64) == 235            # 25 fps x 10 min (BASELINE config 5)
+    assert infer.num_windows(10, 64, 64) == 1
+    all_b = infer.window_batches(15000, 64, 16)
+    assert len(all_b) == 15 and sum(len(b) for b in all_b) == 235 and all_b[-1][-1] == 234 * 64
+    shards = [infer.window_batches(15000, 64, 16, r, 8) for r in range(8)]
+    flat = sorted(s for sh in shards for b in sh for s in b)
+    assert flat == [i * 64 for i in range(235)]
+    rng = np.random.RandomState(0)
+    acc = ScoreAccumulator(100, 7)
+    a, b = rng.rand(64, 7).astype(np.float32), rng.rand(64, 7).astype(np.float32)
+    acc.add(0, a, rng.rand(64, 2).astype(np.float32)); acc.add(64, b, rng.rand(64, 2).astype(np.float32))
+    sc, loc = acc.finish()
+    assert np.array_equal(sc[:64], a) and np.array_equal(sc[64:], b[:36])
+
+
+def test_roofline_accounting_matches_survey_figures():
+    from spot_amd import roofline
+    w = roofline.per_frame_work()
+    assert abs(w["fwd_macs"] / 1e6 - 816.8) < 0.5            # SURVEY: 816.8 MMAC / frame
+    assert abs(w["step_flops"] / 1e9 - 4.90) < 0.01
+    assert 55e6 < w["step_bytes"] < 65e6                        # ~60 MB / frame fwd+bwd
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spot_amd import dp
+    torch.manual_seed(rank)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = dp.BucketReducer(dist, flat)
+    for lo, hi in ((700, 1000), (400, 700), (100, 400), (0, 100)):     # the engine's bucket order: heads first
+        red(lo, hi)
+    red.wait()
+    label = torch.tensor([[0, 1, 0, 3], [0, 0, 2, 0]]) if rank == 0 else torch.tensor([[0, 0, 0, 0], [5, 0, 0, 0]])
+    den = dp.loss_denominators(label, 5.0)
+    dist.all_reduce(den)
+    q.put((rank, flat.clone(), den.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_bucketed_allreduce_and_global_denominators_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(1000, dtype=torch.float32) * 3
+    for rank, flat, den in res:
+        assert torch.equal(flat, want)
+        # 16 frames, 4 events: weights 12*1 + 4*5 = 32
+        assert den.tolist() == [32.0, 4.0]
