@@ -62,15 +62,16 @@ def cpu_baseline():
     x = torch.randn(1, CLIP_LEN, 3, RES, RES, generator=g)
     label = torch.randint(0, NUM_CLASSES, (1, CLIP_LEN), generator=g)
     xy = torch.rand(1, CLIP_LEN, 2, generator=g)
-    O.train_step(om, opt, x, label, xy, NUM_CLASSES)         # warm-up
+    for _ in range(2):                                       # warm-up
+        O.train_step(om, opt, x, label, xy, NUM_CLASSES)
     ts = []
-    for _ in range(2):
+    for _ in range(5):
         t0 = time.perf_counter()
         O.train_step(om, opt, x, label, xy, NUM_CLASSES)
         ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[len(ts) // 2] if len(ts) % 2 else min(ts)
+    t = sorted(ts)[len(ts) // 2]
     return {"value": CLIP_LEN / t, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "1 clip x 64 frames x 224x224, fwd+bwd+AdamW, fp32 torch CPU oracle, best of 2 after 1 warm-up"}
+            "sample": "1 clip x 64 frames x 224x224, fwd+bwd+AdamW, fp32 torch CPU oracle, median of 5 after 2 warm-ups"}
 
 
 def main():
