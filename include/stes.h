@@ -157,7 +157,7 @@ int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, i
  * Xc is the COMPACT copy [B*T*H*W][fold] (NHWC bf16) of the first `fold` channels of the block input.  All tensors keep
  * the SOURCE channel order; the reference's within-group interleave dest(c) (:124-128) is applied by the consumer
  * (stes_cast_bf16 / stes_wgrad `perm_fold`).  fold must be 8 or a multiple of 16 (regnety_008: 8,16,32,80,192).
- *   stes_gsm_prep  : conv3D weight [2][fold/2][27] -> [2][27][fold/2] (layout of the gate kernel's scalar loads)
+ *   stes_gsm_prep  : conv3D weight fp32 [2][fold/2][27] -> bf16 [2][27][fold/2] (layout of the gate kernel's scalar loads)
  *   stes_gsm_gate  : gate[m,2] = tanh(conv3D(relu(scale*x+shift)))    (scale/shift = BatchNorm3d via stes_bn_finalize)
  *   stes_gsm_shift : G[m,c] = y[t+1|t-1] + (x - y), y = gate*x
  *   stes_gsm_bwd_gate : dpre[m,2], gradient at the conv3D output (tanh' applied), from dG (source order)
@@ -166,8 +166,8 @@ int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, i
  *                       (then stes_bn_bwd_reduce / _finalize with D = dxbn, raw1 = Xc)
  *   stes_gsm_bwd_dx   : dXf = dG + gate*(dG[t-+1] - dG) + alpha*dxbn + beta*x + delta                      */
 typedef struct { int32_t B, T, H, W, fold; } stes_gsm_geom;
-int stes_gsm_prep(const float* w3d, float* wt, int fold, void* stream);
-int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const float* wt, const float* b3d,
+int stes_gsm_prep(const float* w3d, uint16_t* wt, int fold, void* stream);
+int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d,
                   float* gate, const stes_gsm_geom* g, void* stream);
 int stes_gsm_shift(const uint16_t* Xc, const float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream);
 int stes_gsm_bwd_gate(const uint16_t* dG, const uint16_t* Xc, const float* gate, float* dpre,

@@ -44,8 +44,9 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
                                                        const float* __restrict__ shift, float* col_sum, float* col_sumsq,
                                                        ConvGeom gm, int n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.y * 4 + wave;
-    if (g >= gm.G) return;
+    __shared__ float red[2][64];
+    const bool active = blockIdx.y * 4 + wave < gm.G;
+    const int g = active ? blockIdx.y * 4 + wave : gm.G - 1;      // idle waves shadow the last group and store nothing
     const int p = lane & 15, q = lane >> 4;
     const int C = gm.C;
     bf16x8 wf[5];
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
 
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t m = (uint32_t)t * 16 + p;
-        const bool valid = m < gm.Md;
+        const bool valid = active && m < gm.Md;
         uint32_t row, wd_, n_, hd_;
         fdivmod(valid ? m : 0u, gm.fd_wd, row, wd_);
         fdivmod(row, gm.fd_hd, n_, hd_);
@@ -117,7 +118,13 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
             float a = ssum[r], b = ssq[r];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (p == 0) { atomicAdd(col_sum + g * 16 + q * 4 + r, a); atomicAdd(col_sumsq + g * 16 + q * 4 + r, b); }
+            if (p == 0) { red[0][wave * 16 + q * 4 + r] = a; red[1][wave * 16 + q * 4 + r] = b; }
+        }
+        __syncthreads();
+        // one contiguous 64-channel atomic per workgroup and statistic instead of 32 four-lane ones
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, c = blockIdx.y * 64 + (threadIdx.x & 63);
+            if (c < gm.C) atomicAdd((which ? col_sumsq : col_sum) + c, red[which][threadIdx.x & 63]);
         }
     }
 }

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
     }
 
     if (stats) {
+        // per-wave column sums -> LDS (the A tile is free: the k loop ended on a barrier) -> one contiguous atomic per column
+        // per workgroup; scattered few-lane atomics on a handful of cache lines serialise in L2
+        float* red = reinterpret_cast<float*>(&As[0][0]);      // [2 (wm)][2 (sum, sumsq)][BN]
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -243,9 +246,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
                 float s = csum[i][r], q = csq[i][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-                const int n = n0 + wn * (BN / 2) + i * 16 + fq * 4 + r;
-                if (fr == 0 && n < N) { atomicAdd(p.col_sum + n, s); atomicAdd(p.col_sumsq + n, q); }
+                const int nl = wn * (BN / 2) + i * 16 + fq * 4 + r;
+                if (fr == 0) { red[(wm * 2 + 0) * BN + nl] = s; red[(wm * 2 + 1) * BN + nl] = q; }
             }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int which = t / BN, nl = t - which * BN;
+            if (n0 + nl < N) atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[which * BN + nl] + red[(2 + which) * BN + nl]);
+        }
     }
 }
 

@@ -34,73 +34,161 @@ __device__ __forceinline__ int dest_of(int c, int fold) {
     return g * half + 2 * j + i;
 }
 
-// ------------------------------------------------------------------ weight prep: [2][half][27] -> [2][27][half]
-__global__ void gsm_prep_kernel(const float* __restrict__ w, float* __restrict__ wt, int half) {
+// ------------------------------------------------------------------ weight prep: fp32 [2][half][27] -> bf16 [2][27][half]
+__global__ void gsm_prep_kernel(const float* __restrict__ w, bf16* __restrict__ wt, int half) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * half * 27) return;
     const int tap = i % 27, c = (i / 27) % half, g = i / (27 * half);
-    wt[((long)g * 27 + tap) * half + c] = w[i];
+    wt[((long)g * 27 + tap) * half + c] = (bf16)w[i];
 }
 
 // ------------------------------------------------------------------ gate
-// V = channels per vector (4 when half == 4, else 8).  grid (row tiles, T, B*2)
-template <int V>
+// Workgroup = (row tile, frame segment, clip).  It walks its frames with a three-slot ring of BN+ReLU'd halo tiles in LDS
+// (all `fold` channels of a position side by side), so every input frame is fetched once per workgroup; the next frame's
+// tile travels global -> registers while the current frame is convolved.  Waves 0,1 evaluate group 0, waves 2,3 group 1:
+// the conv weights (bf16 pairs) are wave-uniform scalar loads feeding v_dot2c_f32_bf16.
+struct GateTile {
+    int TH, TSEG, PS;                  // rows per tile, frames per segment, LDS position stride in 16-byte units
+    FastDiv fd_nch, fd_W2, fd_spr;     // 16-byte chunks per position, W + 2, output strips per row
+};
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+#ifdef STES_GATE_NO_DOT2
+    return acc + __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+#else
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "s"(b), "v"(a));
+    return acc;
+#endif
+}
+
+template <int V, int WB>   // V: channels per LDS read (4 when half == 4, else 8); WB: outputs per thread along w (4 or 1)
 __global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ Xc, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ wt,
-                                                       const float* __restrict__ b3d, float* __restrict__ gate, Geom gm, int TH) {
+                                                       const float* __restrict__ shift, const uint32_t* __restrict__ wt,
+                                                       const float* __restrict__ b3d, float* __restrict__ gate, Geom gm, GateTile gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __bf16 vecb __attribute__((ext_vector_type(V)));
-    const int fold = gm.fold, half = fold >> 1;
-    const int grp = blockIdx.z & 1, b = blockIdx.z >> 1, t = blockIdx.y, h0 = blockIdx.x * TH;
-    const int W = gm.W, H = gm.H, W2 = W + 2, rows = TH + 2;
-    bf16* tile = (bf16*)smem;                              // [3][rows][W2][half]
-    const int nchunk = half / V;
+    constexpr int MAXI = 8;
+    const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
+    const int W = gm.W, H = gm.H, T = gm.T, W2 = W + 2, rows = gt.TH + 2;
+    const int h0 = blockIdx.x * gt.TH, t0 = blockIdx.y * gt.TSEG, b = blockIdx.z;
+    const int t1 = (t0 + gt.TSEG < T) ? t0 + gt.TSEG : T;
+    const int slot_bytes = (rows * W2 + 4) * gt.PS * 16;      // + 4 positions of slack for ragged strips
+    float* sc_s = reinterpret_cast<float*>(smem + 3 * slot_bytes);
+    float* sh_s = sc_s + fold;
+    for (int i = threadIdx.x; i < fold; i += 256) { sc_s[i] = scale[i]; sh_s[i] = shift[i]; }
     const long plane = (long)H * W;
-    const float* sc = scale + grp * half;
-    const float* sh = shift + grp * half;
-    // stage: zero everything that is outside the clip / image, BN + ReLU the rest
-    const int items = 3 * rows * W2 * nchunk;
-    for (int i = threadIdx.x; i < items; i += 256) {
-        const int ch = i % nchunk; int r = i / nchunk;
-        const int wp = r % W2; r /= W2;
-        const int hr = r % rows, kt = r / rows;
-        const int tt = t + kt - 1, hh = h0 + hr - 1, ww = wp - 1;
-        vecb v;
+    const int items = rows * W2 * nch;
+
+    // per-thread staging slots: global element offset inside a frame (-1: zero padding), LDS byte offset, first channel
+    int goff[MAXI], loff[MAXI], ch0[MAXI];
 #pragma unroll
-        for (int k = 0; k < V; ++k) v[k] = (bf16)0.f;
-        if (tt >= 0 && tt < gm.T && hh >= 0 && hh < H && ww >= 0 && ww < W) {
-            const long m = ((long)(b * gm.T + tt)) * plane + (long)hh * W + ww;
-            const vecb x = *reinterpret_cast<const vecb*>(Xc + m * fold + grp * half + ch * V);
-#pragma unroll
-            for (int k = 0; k < V; ++k) v[k] = (bf16)fmaxf((float)x[k] * sc[ch * V + k] + sh[ch * V + k], 0.f);
+    for (int k = 0; k < MAXI; ++k) {
+        const int i = threadIdx.x + k * 256;
+        goff[k] = -1; loff[k] = -1; ch0[k] = 0;
+        if (i < items) {
+            uint32_t pos, ch, hr, wp;
+            fdivmod((uint32_t)i, gt.fd_nch, pos, ch);
+            fdivmod(pos, gt.fd_W2, hr, wp);
+            const int hh = h0 + (int)hr - 1, ww = (int)wp - 1;
+            loff[k] = ((int)pos * gt.PS + (int)ch) * 16;
+            ch0[k] = (int)ch * 8;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) goff[k] = (hh * W + ww) * fold + (int)ch * 8;
         }
-        *reinterpret_cast<vecb*>(tile + (((long)kt * rows + hr) * W2 + wp) * half + ch * V) = v;
     }
-    __syncthreads();
+    bf16x8 stage[MAXI];
+    auto fetch = [&](int f) {           // frame f of this clip -> registers (zeros outside the clip)
+        const bool live = f >= 0 && f < T;
+        const bf16* base = Xc + ((long)b * T + (live ? f : 0)) * plane * fold;
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) stage[k] = (live && goff[k] >= 0) ? *reinterpret_cast<const bf16x8*>(base + goff[k]) : zero8();
+        return live;
+    };
+    auto commit = [&](int f, bool live) {   // registers -> BN + ReLU -> ring slot f mod 3; padding stays exactly zero
+        unsigned char* slot = smem + ((f + 3) % 3) * slot_bytes;
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            if (loff[k] < 0) continue;
+            bf16x8 v = stage[k];
+            if (live && goff[k] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf((float)v[e] * sc_s[ch0[k] + e] + sh_s[ch0[k] + e], 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(slot + loff[k]) = v;
+        }
+    };
+
+    __syncthreads();                     // scale/shift visible
+    bool live = fetch(t0 - 1); commit(t0 - 1, live);
+    live = fetch(t0); commit(t0, live);
+    live = fetch(t0 + 1);
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7), tg = threadIdx.x & 127;     // wave-uniform -> SGPR
     const float bias = b3d[grp];
-    const float* wg = wt + (long)grp * 27 * half;          // [27][half], wave-uniform -> scalar loads
-    const int nout = TH * W;
-    for (int o = threadIdx.x; o < nout; o += 256) {
-        const int hr = o / W, ww = o - hr * W;
-        const int hh = h0 + hr;
-        if (hh >= H) continue;
-        float acc = bias;
+    const uint32_t* wg = wt + (grp * 27 * half) / 2;      // [27][half/2] bf16 pairs, wave-uniform
+    const int nstrips = gt.TH * (int)gt.fd_spr.d;
+    const int pstride = gt.PS * 16;
+    typedef uint32_t xvec __attribute__((ext_vector_type(V / 2)));
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                 // frame t-2's slot is no longer read
+        commit(t + 1, live);
+        __syncthreads();
+        if (t + 1 < t1) live = fetch(t + 2);
+        const unsigned char* s0 = smem + ((t + 2) % 3) * slot_bytes;     // frame t-1
+        const unsigned char* s1 = smem + (t % 3) * slot_bytes;
+        const unsigned char* s2 = smem + ((t + 1) % 3) * slot_bytes;
+        for (int s = tg; s < nstrips; s += 128) {
+            uint32_t hr, sw;
+            fdivmod((uint32_t)s, gt.fd_spr, hr, sw);
+            const int hh = h0 + (int)hr, w0 = (int)sw * WB;
+            if (hh >= H) break;
+            // WB == 4: one accumulator per output of the strip; WB == 1: four partial sums of the one output --
+            // either way four independent v_dot2c chains
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
+            for (int kt = 0; kt < 3; ++kt) {
+                const unsigned char* sl = kt == 0 ? s0 : (kt == 1 ? s1 : s2);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const bf16* p = tile + (((long)kt * rows + hr + kh) * W2 + ww + kw) * half;
-                    const float* wv = wg + ((kt * 3 + kh) * 3 + kw) * half;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const unsigned char* rowp = sl + (((int)hr + kh) * W2 + w0) * pstride + grp * half * 2;
+                    const uint32_t* wrow = wg + (((kt * 3 + kh) * 3) * half) / 2;
                     for (int c = 0; c < half; c += V) {
-                        const vecb x = *reinterpret_cast<const vecb*>(p + c);
+                        if (WB == 4) {
+                            xvec x[6];
 #pragma unroll
-                        for (int k = 0; k < V; ++k) acc += wv[c + k] * (float)x[k];
+                            for (int j = 0; j < 6; ++j) x[j] = *reinterpret_cast<const xvec*>(rowp + j * pstride + c * 2);
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                                for (int e = 0; e < V / 2; ++e) {
+                                    const uint32_t wv = wrow[(kw * half + c) / 2 + e];
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) acc[o] = dot2_bf16(x[o + kw][e], wv, acc[o]);
+                                }
+                        } else {
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) {
+                                const xvec x = *reinterpret_cast<const xvec*>(rowp + kw * pstride + c * 2);
+#pragma unroll
+                                for (int e = 0; e < V / 2; ++e) {
+                                    const int a = V == 4 ? ((kw & 1) * 2 + e) : e;        // four independent chains either way
+                                    acc[a] = dot2_bf16(x[e], wrow[(kw * half + c) / 2 + e], acc[a]);
+                                }
+                            }
+                        }
                     }
                 }
-        const long m = ((long)(b * gm.T + t)) * plane + (long)hh * W + ww;
-        gate[m * 2 + grp] = tanhf(acc);
+            }
+            // the dot instructions are opaque to the compiler's hazard recogniser: a different VALU opcode may not read or
+            // overwrite a v_dot2c result for 4 wait states, so drain the pipeline before the accumulators are consumed
+            asm volatile("s_nop 4" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            const long m = ((long)b * T + t) * plane + (long)hh * W + w0;
+            if (WB == 4) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (w0 + o < W) gate[(m + o) * 2 + grp] = tanhf(acc[o] + bias);
+            } else {
+                gate[m * 2 + grp] = tanhf((acc[0] + acc[1]) + (acc[2] + acc[3]) + bias);
+            }
+        }
     }
 }
 
@@ -179,124 +267,156 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restric
 // grid (workgroups, 2 groups); each workgroup walks 32-position chunks and keeps its accumulators in registers.
 __device__ __forceinline__ int rho32(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
-template <int NCT>     // channel tiles of 16 per group (half <= 16*NCT)
+template <int NCT, int POS>   // NCT: 16-channel tiles per group (half <= 16*NCT); POS: positions per wave pass
 __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ dw, float* __restrict__ db, Geom gm, long n_chunks) {
-    constexpr int CP = NCT * 16;                                   // padded channels
-    constexpr int LDX = CP + 16;
-    __shared__ __attribute__((aligned(16))) bf16 Dm[4][32 * 48];   // per wave: [32 pos (rho)][32 taps + 16 pad]
-    __shared__ __attribute__((aligned(16))) bf16 Xb[4][32 * LDX];  // per wave: [32 pos (rho)][CP + 16 pad]
-    static_assert(sizeof(bf16) * 4 * 32 * LDX >= sizeof(float) * CP * 27, "result staging must fit the operand buffer");
+                                                            float* __restrict__ dw, float* __restrict__ db, Geom gm, long n_chunks,
+                                                            FastDiv fd_nch8) {
+    // POS == 64: lane = position, one 8-byte load brings the gate gradient of both groups, the groups take turns in the
+    //            Dm buffer;  POS == 32: lane = (position, group), both groups' Dm rows are live together.
+    constexpr int LDD = 48;                                        // Dm row: 32 taps + 16 pad (elements)
+    constexpr int LDX = 32 * NCT + 16;                             // Xb row: both groups' channels + tile overhang + pad
+    __shared__ __attribute__((aligned(16))) bf16 Dm[4][64 * LDD];  // per wave: [64 rows (rho within 32)][taps]
+    __shared__ __attribute__((aligned(16))) bf16 Xb[4][POS * LDX]; // per wave: [POS positions (rho within 32)][channels]
+    static_assert(sizeof(bf16) * 4 * POS * LDX >= sizeof(float) * 32 * NCT * 27, "result staging must fit the operand buffer");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int grp = blockIdx.y;
-    const int fold = gm.fold, half = fold >> 1;
+    const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
     const int H = gm.H, W = gm.W, T = gm.T;
     const long plane = (long)H * W;
-    f32x4 acc[2][NCT];
+    f32x4 acc[2][2][NCT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) acc[g][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum0 = 0.f, bsum1 = 0.f;
     bf16* dm = Dm[wave];
     bf16* xb = Xb[wave];
-    // every wave owns whole chunks: no workgroup barriers, only wave-local LDS traffic
-    const long wstride = (long)gridDim.x * 4;
-    for (long ck = (long)blockIdx.x * 4 + wave; ck < n_chunks; ck += wstride) {
-        const long p0 = ck * 32;
-        // lane -> (position lane>>1, tap half lane&1): builds 16 taps of one position of Dm
-        {
-            const int pl = lane >> 1, th = lane & 1;
-            const long m = p0 + pl;
-            bf16 vals[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) vals[k] = (bf16)0.f;
-            if (m < gm.M) {
-                uint32_t r1, w_u, r2, h_u;
-                fdivmod((uint32_t)m, gm.fd_W, r1, w_u);
-                fdivmod(r1, gm.fd_H, r2, h_u);
-                const int w_ = (int)w_u, h_ = (int)h_u, t_ = (int)(r2 - fdiv(r2, gm.fd_T) * T);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int tap = th * 16 + k;
-                    if (tap < 27) {
-                        const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                        // xbr at p contributes to output position p - (k - 1)
-                        const int to = t_ - (kt - 1), ho = h_ - (kh - 1), wo = w_ - (kw - 1);
-                        if (to >= 0 && to < T && ho >= 0 && ho < H && wo >= 0 && wo < W)
-                            vals[k] = (bf16)dpre[(m - (long)(kt - 1) * plane - (long)(kh - 1) * W - (kw - 1)) * 2 + grp];
-                    }
-                }
-                if (th == 0) bsum += dpre[m * 2 + grp];
-            }
-            bf16x8* dst = reinterpret_cast<bf16x8*>(dm + rho32(pl) * 48 + th * 16);
-            bf16x8 v0, v1;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v0[k] = vals[k]; v1[k] = vals[8 + k]; }
-            dst[0] = v0; dst[1] = v1;
-        }
-        // Xb: relu(bn(x)) for 32 positions x CP channels, 8 channels per item
-        for (int i = lane; i < 32 * (CP / 8); i += 64) {
-            const int pl = i / (CP / 8), c0 = (i % (CP / 8)) * 8;
-            const long m = p0 + pl;
-            bf16x8 v = zero8();
-            if (m < gm.M && c0 < half) {
-                if (half >= 8) {
-                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(Xc + m * fold + grp * half + c0);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (bf16)fmaxf((float)x[k] * scale[grp * half + c0 + k] + shift[grp * half + c0 + k], 0.f);
-                } else {        // half == 4
-                    const bf16x4 x = *reinterpret_cast<const bf16x4*>(Xc + m * fold + grp * half);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (bf16)fmaxf((float)x[k] * scale[grp * half + k] + shift[grp * half + k], 0.f);
-                }
-            }
-            *reinterpret_cast<bf16x8*>(xb + rho32(pl) * LDX + c0) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int r_lo = rho32(8 * fq + (fr >> 2)), r_hi = rho32(8 * fq + (fr >> 2) + 4);
-        const int cc = 4 * (fr & 3);
+    const int r_lo = rho32(8 * fq + (fr >> 2)), r_hi = rho32(8 * fq + (fr >> 2) + 4);
+    const int cc = 4 * (fr & 3);
+    const int pl = POS == 64 ? lane : (lane & 31), lg = POS == 64 ? 0 : (lane >> 5);
+    const int my_row = (pl & 32) + rho32(pl & 31);
+
+    auto mma = [&](int g, int dm_row0, int x_row0) {
         bf16x8 fa[2], fb[NCT];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + r_lo * 48 + i * 16 + cc));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + r_hi * 48 + i * 16 + cc));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + (dm_row0 + r_lo) * LDD + i * 16 + cc));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(dm + (dm_row0 + r_hi) * LDD + i * 16 + cc));
             fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + r_lo * LDX + j * 16 + cc));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + r_hi * LDX + j * 16 + cc));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + (x_row0 + r_lo) * LDX + g * half + j * 16 + cc));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + (x_row0 + r_hi) * LDX + g * half + j * 16 + cc));
             fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // reduce the four waves in LDS, laid out as the checkpoint tensor [c][27] of this group, then contiguous atomics
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(&Xb[0][0]);              // >= half*27 floats (CP*27*4 <= sizeof(Xb))
-    for (int i = threadIdx.x; i < half * 27; i += 256) red[i] = 0.f;
-    __syncthreads();
+            for (int j = 0; j < NCT; ++j) acc[g][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[g][i][j], 0, 0, 0);
+    };
+    auto put_row = [&](int row, const bf16 (&v)[32]) {
+        bf16x8* dst = reinterpret_cast<bf16x8*>(dm + row * LDD);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < NCT; ++j)
+            for (int k = 0; k < 8; ++k) o[k] = v[q * 8 + k];
+            dst[q] = o;
+        }
+    };
+
+    // every wave owns whole chunks: no workgroup barriers inside the loop, only wave-local LDS traffic
+    const long wstride = (long)gridDim.x * 4;
+    for (long ck = (long)blockIdx.x * 4 + wave; ck < n_chunks; ck += wstride) {
+        const long p0 = ck * POS;
+        const long m = p0 + pl;
+        const bool in = m < gm.M;
+        uint32_t r1, w_u, r2, h_u;
+        fdivmod(in ? (uint32_t)m : 0u, gm.fd_W, r1, w_u);
+        fdivmod(r1, gm.fd_H, r2, h_u);
+        const int w_ = (int)w_u, h_ = (int)h_u, t_ = (int)(r2 - fdiv(r2, gm.fd_T) * T);
+        // tap k reads the gate gradient at offset -(k - 1): k = 0 needs coordinate + 1 inside, k = 2 needs coordinate - 1 inside
+        const bool vt[3] = {t_ + 1 < T, true, t_ >= 1}, vh[3] = {h_ + 1 < H, true, h_ >= 1}, vw[3] = {w_ + 1 < W, true, w_ >= 1};
+        bf16 v0[32], v1[32];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tap = i * 16 + fq * 4 + r, c = j * 16 + fr;
-                if (tap < 27 && c < half) atomicAdd(&red[c * 27 + tap], acc[i][j][r]);
+        for (int tap = 0; tap < 32; ++tap) {
+            float a = 0.f, b = 0.f;
+            if (tap < 27) {
+                const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const bool ok = in && vt[kt] && vh[kh] && vw[kw];
+                const long src = ok ? m - (long)(kt - 1) * plane - (long)(kh - 1) * W - (kw - 1) : (in ? m : 0);
+                if (POS == 64) {
+                    const float2 d = *reinterpret_cast<const float2*>(dpre + src * 2);
+                    a = ok ? d.x : 0.f; b = ok ? d.y : 0.f;
+                } else {
+                    const float d = dpre[src * 2 + lg];
+                    a = ok ? d : 0.f;
+                }
+                if (tap == 13) { bsum0 += a; bsum1 += b; }
             }
+            v0[tap] = (bf16)a; v1[tap] = (bf16)b;
+        }
+        // Xb: relu(bn(x)) for POS positions x fold channels, 8 channels per item (coalesced over the compact rows)
+        for (int i = lane; i < POS * nch; i += 64) {
+            const int ps = (int)fdiv((uint32_t)i, fd_nch8), c0 = (i - ps * nch) * 8;
+            const long mm = p0 + ps;
+            bf16x8 v = zero8();
+            if (mm < gm.M) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(Xc + mm * fold + c0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (bf16)fmaxf((float)x[k] * scale[c0 + k] + shift[c0 + k], 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(xb + ((ps & 32) + rho32(ps & 31)) * LDX + c0) = v;
+        }
+        if (POS == 64) {
+            put_row(my_row, v0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mma(0, 0, 0); mma(0, 32, 32);
+            __builtin_amdgcn_wave_barrier();
+            put_row(my_row, v1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mma(1, 0, 0); mma(1, 32, 32);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            put_row(lg * 32 + my_row, v0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mma(0, 0, 0); mma(1, 32, 0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // reduce the four waves in LDS, laid out as the parameter tensor [2][half][27], then contiguous atomics
     __syncthreads();
-    float* dst = dw + (long)grp * half * 27;
-    for (int i = threadIdx.x; i < half * 27; i += 256) atomicAdd(dst + i, red[i]);
-    bsum = wave_sum(bsum);
-    if (lane == 0) atomicAdd(db + grp, bsum);
+    float* red = reinterpret_cast<float*>(&Xb[0][0]);
+    for (int i = threadIdx.x; i < fold * 27; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tap = i * 16 + fq * 4 + r, c = j * 16 + fr;
+                    if (tap < 27 && c < half) atomicAdd(&red[(g * half + c) * 27 + tap], acc[g][i][j][r]);
+                }
+    __syncthreads();
+    for (int i = threadIdx.x; i < fold * 27; i += 256) atomicAdd(dw + i, red[i]);
+    if (POS == 64) {
+        bsum0 = wave_sum(bsum0); bsum1 = wave_sum(bsum1);
+        if (lane == 0) { atomicAdd(db, bsum0); atomicAdd(db + 1, bsum1); }
+    } else {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) bsum0 += __shfl_xor(bsum0, o, 64);
+        if ((lane & 31) == 0) atomicAdd(db + lg, bsum0);
+    }
 }
 
 // ------------------------------------------------------------------ backward: gradient at the BatchNorm3d output
@@ -476,28 +596,56 @@ int tile_rows(const Geom& gm, int bytes_per_pos) {
 
 #define S(s) ((hipStream_t)(s))
 
-extern "C" int stes_gsm_prep(const float* w3d, float* wt, int fold, void* stream) {
+extern "C" int stes_gsm_prep(const float* w3d, uint16_t* wt, int fold, void* stream) {
     STES_CHECK(w3d && wt && fold >= 8, STES_ERR_ARG, "stes_gsm_prep: bad argument");
     const int n = fold * 27;
-    hipLaunchKernelGGL(gsm_prep_kernel, dim3(stes_div_up(n, 256)), dim3(256), 0, S(stream), w3d, wt, fold / 2);
+    hipLaunchKernelGGL(gsm_prep_kernel, dim3(stes_div_up(n, 256)), dim3(256), 0, S(stream), w3d, (bf16*)wt, fold / 2);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const float* wt, const float* b3d,
+extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d,
                              float* gate, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
     STES_CHECK(Xc && scale && shift && wt && b3d && gate, STES_ERR_ARG, "stes_gsm_gate: null pointer");
     const Geom gm = to_geom(g);
-    const int half = gm.fold / 2;
-    const int th = tile_rows(gm, half * 2);
-    const size_t lds = (size_t)3 * (th + 2) * (gm.W + 2) * half * 2;
-    STES_CHECK(lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_gate: image row too wide for the LDS tile");
-    const dim3 grid(stes_div_up(gm.H, th), gm.T, gm.B * 2);
-    if (half == 4)
-        hipLaunchKernelGGL(gsm_gate_kernel<4>, grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, wt, b3d, gate, gm, th);
-    else
-        hipLaunchKernelGGL(gsm_gate_kernel<8>, grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, wt, b3d, gate, gm, th);
+    const int nch = gm.fold / 8;
+    GateTile gt;
+    gt.PS = (nch >= 4 && nch % 2 == 0) ? nch + 1 : nch;         // odd 16-byte stride: conflict-free ds_read_b128 across positions
+    const int wb = gm.W >= 28 ? 4 : 1, spr = stes_div_up(gm.W, wb);
+    // + 4 positions: the last strip of a ragged row may read (and discard) past the tile's end
+    auto slot = [&](int t) { return (size_t)((t + 2) * (gm.W + 2) + 4) * gt.PS * 16; };
+    auto fits = [&](int t) { return 3 * slot(t) <= 72 * 1024 && (long)(t + 2) * (gm.W + 2) * nch <= 8 * 256; };
+    // rows per tile: best product of thread utilisation (128 threads per group walk TH*spr strips), row-tile
+    // quantisation and halo overhead
+    int th = 1; double best = -1.0;
+    for (int t = 1; t <= gm.H; ++t) {
+        if (!fits(t)) break;
+        const int strips = t * spr;
+        const double eff = (double)strips / (128.0 * stes_div_up(strips, 128)) * gm.H / ((double)t * stes_div_up(gm.H, t)) * t / (t + 2.0);
+        if (eff > best) { best = eff; th = t; }
+    }
+    STES_CHECK(fits(th), STES_ERR_UNSUPPORTED, "stes_gsm_gate: image row too wide for the LDS tile");
+    const int rt = stes_div_up(gm.H, th);
+    int tseg = gm.T;
+    while (tseg > 4 && (long)rt * gm.B * stes_div_up(gm.T, tseg) < 512) tseg = (tseg + 1) / 2;
+    gt.TH = th; gt.TSEG = tseg;
+    gt.fd_nch = make_fastdiv(nch); gt.fd_W2 = make_fastdiv(gm.W + 2); gt.fd_spr = make_fastdiv(spr);
+    const size_t lds = 3 * slot(th) + (size_t)gm.fold * 2 * sizeof(float);
+    const dim3 grid(rt, stes_div_up(gm.T, tseg), gm.B);
+    static const bool big_lds = [] {     // tiles beyond the default 64 KiB dynamic-LDS limit
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        return ok;
+    }();
+    STES_CHECK(big_lds || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_gate: cannot raise the dynamic LDS limit");
+#define LAUNCH_GATE(V, WB) hipLaunchKernelGGL((gsm_gate_kernel<V, WB>), grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, (const uint32_t*)wt, b3d, gate, gm, gt)
+    if (gm.fold == 8) { if (wb == 4) LAUNCH_GATE(4, 4); else LAUNCH_GATE(4, 1); }
+    else { if (wb == 4) LAUNCH_GATE(8, 4); else LAUNCH_GATE(8, 1); }
+#undef LAUNCH_GATE
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -532,18 +680,20 @@ extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const f
     STES_CHECK(dpre && Xc && scale && shift && dw && db, STES_ERR_ARG, "stes_gsm_bwd_wgrad: null pointer");
     const Geom gm = to_geom(g);
     const int half = gm.fold / 2;
-    const long n_chunks = (gm.M + 31) / 32;
-    long gx = (n_chunks + 31) / 32; if (gx > 1024) gx = 1024;       // >= 8 chunks of 32 rows per wave
-    const dim3 grid((int)gx, 2);
     const int nct = (half + 15) / 16;
-#define LAUNCH_WG(N) hipLaunchKernelGGL(gsm_bwd_wgrad_kernel<N>, grid, dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks)
+    const int pos = nct == 1 ? 64 : 32;
+    const long n_chunks = (gm.M + pos - 1) / pos;
+    long gx = (n_chunks + 31) / 32; if (gx > 1024) gx = 1024;       // >= 8 chunks per wave
+    const dim3 grid((int)gx);
+    const FastDiv fd_nch8 = make_fastdiv(gm.fold / 8);
+#define LAUNCH_WG(N, P) hipLaunchKernelGGL((gsm_bwd_wgrad_kernel<N, P>), grid, dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks, fd_nch8)
     switch (nct) {
-        case 1: LAUNCH_WG(1); break;
-        case 2: LAUNCH_WG(2); break;
-        case 3: LAUNCH_WG(3); break;
-        case 4: LAUNCH_WG(4); break;
-        case 5: LAUNCH_WG(5); break;
-        default: LAUNCH_WG(6); break;
+        case 1: LAUNCH_WG(1, 64); break;
+        case 2: LAUNCH_WG(2, 32); break;
+        case 3: LAUNCH_WG(3, 32); break;
+        case 4: LAUNCH_WG(4, 32); break;
+        case 5: LAUNCH_WG(5, 32); break;
+        default: LAUNCH_WG(6, 32); break;
     }
 #undef LAUNCH_WG
     STES_LAUNCH_CHECK();

@@ -107,7 +107,7 @@ class Block:
         if self.kind == "gsm":
             self.gsm = c1.gsm
             self.bng = BN(eng, c1.gsm.bn)
-            self.wt = torch.zeros(27 * self.fold, device=eng.dev)
+            self.wt = torch.zeros(27 * self.fold, dtype=torch.bfloat16, device=eng.dev)
             eng.gsm_preps.append((c1.gsm.conv3D.weight, self.wt, self.fold))
         elif self.kind == "tsm":
             self.tsm_fold = self.cin // c1.fold_div
