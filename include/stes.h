@@ -46,12 +46,13 @@ typedef struct {
     const float* a_gate; int32_t gate_group;
     int32_t map_stride, Ho, Wo, Hi, Wi;
     const uint16_t* W;  int64_t ldw;
-    const float* bias;  int32_t act;          /* 0 none, 1 relu */
+    const float* bias;  int32_t act;          /* 0 none, 1 relu, 2 sigmoid */
     void* C; int64_t ldc; int32_t c_f32;      /* output bf16 (0) or f32 (1) */
     float* col_sum; float* col_sumsq;
     const uint16_t* relu_mask; int64_t ldmask; /* optional: C[m,n] = 0 where relu_mask[m,n] <= 0 (ReLU backward) */
     uint16_t* C0; int64_t ldc0; int32_t n_split; /* optional: columns [0,n_split) go to the compact bf16 tensor C0 instead */
     int64_t M; int32_t N; int32_t K;
+    float out_scale;                          /* C = act(out_scale * pro(A) W^T + bias); 0 means 1 */
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
@@ -97,13 +98,11 @@ int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shi
 int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, const uint16_t* mul, float* out,
                    uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream);
 
-/* timm SEModule excite: hidden = relu(w1 pooled + b1); gate = sigmoid(w2 hidden + b2). */
-int stes_se_fc(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-               float* hidden, float* gate, int N, int C, int R, void* stream);
-int stes_se_fc_bwd(const float* dgate_raw, const float* gate, const float* hidden, const float* w1, const float* w2,
-                   float* dpre2, float* dpre1, float* dpool, float inv_hw, int N, int C, int R, void* stream);
-/* dW[n1,n2] += P[N,n1]^T Q[N,n2], db[n1] += colsum(P): fp32 weight gradients of the SE FCs. */
-int stes_f32_outer(const float* P, const float* Q, float* dW, float* db, int N, int n1, int n2, void* stream);
+/* Squeeze-excite (timm SEModule inside regnety_008's Bottleneck: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid) runs on
+ * stes_chan_pool + two stes_gemm calls (bias + ReLU / sigmoid epilogues); its backward on stes_sigmoid_bwd + two
+ * stes_gemm (relu_mask, out_scale = 1/HW) + two stes_wgrad calls.
+ * stes_sigmoid_bwd: out[i] = bf16(d[i] * g[i] * (1 - g[i])), the gradient at the sigmoid's input.                */
+int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream);
 
 /* BatchNorm backward.  The incoming gradient is formed on the fly:
  *   dY = (D * mul[m/group] + add[m/group]) * [act_scale*act_raw + act_shift > 0]

@@ -34,6 +34,18 @@ __device__ __forceinline__ bf16x8 zero8() {
     return v;
 }
 
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[i + 4] = b[i]; }
+}
+__device__ __forceinline__ void load8b(const bf16* p, float (&f)[8]) {
+    unpack8(*reinterpret_cast<const bf16x8*>(p), f);
+}
+__device__ __forceinline__ void store8b(bf16* p, const float (&f)[8]) {
+    *reinterpret_cast<bf16x8*>(p) = pack8(f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -23,17 +23,6 @@ __host__ int flat_grid(long rows, int ch, int max_blocks = 2048) {
     return (int)g;
 }
 
-__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[i + 4] = b[i]; }
-}
-__device__ __forceinline__ void load8b(const bf16* p, float (&f)[8]) {
-    unpack8(*reinterpret_cast<const bf16x8*>(p), f);
-}
-__device__ __forceinline__ void store8b(bf16* p, const float (&f)[8]) {
-    *reinterpret_cast<bf16x8*>(p) = pack8(f);
-}
 
 // ---------------------------------------------------------------- BN finalize
 __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, double count, const float* gamma,
@@ -166,78 +155,10 @@ __global__ void chan_pool_kernel(const bf16* __restrict__ c, const float* __rest
     }
 }
 
-// ---------------------------------------------------------------- squeeze-excite FC (per image)
-__global__ __launch_bounds__(TPB) void se_fc_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
-                                                    const float* __restrict__ b1, const float* __restrict__ w2,
-                                                    const float* __restrict__ b2, float* __restrict__ hidden,
-                                                    float* __restrict__ gate, int C, int R) {
-    extern __shared__ float lds[];     // pooled[C] + hidden[R]
-    float* sp = lds; float* sh = lds + C;
-    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < C; i += TPB) sp[i] = pooled[(long)n * C + i];
-    __syncthreads();
-    for (int r = wave; r < R; r += TPB / 64) {
-        float a = 0.f;
-        for (int k = lane; k < C; k += 64) a += w1[(long)r * C + k] * sp[k];
-        a = wave_sum(a);
-        if (lane == 0) { a = fmaxf(a + b1[r], 0.f); sh[r] = a; hidden[(long)n * R + r] = a; }
-    }
-    __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += TPB) {
-        float a = b2[ch];
-        for (int r = 0; r < R; ++r) a += w2[(long)ch * R + r] * sh[r];
-        gate[(long)n * C + ch] = 1.f / (1.f + __expf(-a));
-    }
-}
-
-__global__ __launch_bounds__(TPB) void se_fc_bwd_kernel(const float* __restrict__ dgate_raw, const float* __restrict__ gate,
-                                                        const float* __restrict__ hidden, const float* __restrict__ w1,
-                                                        const float* __restrict__ w2, float* __restrict__ dpre2,
-                                                        float* __restrict__ dpre1, float* __restrict__ dpool,
-                                                        float inv_hw, int C, int R) {
-    extern __shared__ float lds[];     // d2[C] + d1[R]
-    float* s2 = lds; float* s1 = lds + C;
-    const int n = blockIdx.x;
-    for (int ch = threadIdx.x; ch < C; ch += TPB) {
-        const float g = gate[(long)n * C + ch];
-        const float d = dgate_raw[(long)n * C + ch] * g * (1.f - g);
-        s2[ch] = d; dpre2[(long)n * C + ch] = d;
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < R; r += TPB) {
-        float a = 0.f;
-        for (int ch = 0; ch < C; ++ch) a += w2[(long)ch * R + r] * s2[ch];
-        a = hidden[(long)n * R + r] > 0.f ? a : 0.f;
-        s1[r] = a; dpre1[(long)n * R + r] = a;
-    }
-    __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += TPB) {
-        float a = 0.f;
-        for (int r = 0; r < R; ++r) a += w1[(long)r * C + ch] * s1[r];
-        dpool[(long)n * C + ch] = a * inv_hw;
-    }
-}
-
-// dW[n1,n2] += sum_n P[n,n1] Q[n,n2];  db[n1] += sum_n P[n,n1]   (fp32, small)
-__global__ __launch_bounds__(TPB) void f32_outer_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                        float* __restrict__ dW, float* __restrict__ db, int N, int n1, int n2) {
-    __shared__ float sp[32][17], sq[32][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
-    float acc = 0.f, bacc = 0.f;
-    for (int nb = 0; nb < N; nb += 32) {
-        for (int e = threadIdx.x; e < 512; e += TPB) {
-            const int r = e >> 4, cc = e & 15, n = nb + r;
-            sp[r][cc] = (n < N && i0 + cc < n1) ? P[(long)n * n1 + i0 + cc] : 0.f;
-            sq[r][cc] = (n < N && j0 + cc < n2) ? Q[(long)n * n2 + j0 + cc] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int r = 0; r < 32; ++r) { acc += sp[r][ty] * sq[r][tx]; bacc += sp[r][ty]; }
-        __syncthreads();
-    }
-    if (i0 + ty < n1 && j0 + tx < n2) dW[(long)(i0 + ty) * n2 + j0 + tx] += acc;
-    if (db && blockIdx.y == 0 && tx == 0 && i0 + ty < n1) db[i0 + ty] += bacc;
+// ---------------------------------------------------------------- sigmoid backward (squeeze-excite gate)
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ d, const float* __restrict__ g, bf16* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float gv = g[i]; out[i] = (bf16)(d[i] * gv * (1.f - gv)); }
 }
 
 // ---------------------------------------------------------------- BN backward
@@ -457,26 +378,9 @@ extern "C" int stes_chan_pool(const uint16_t* c, const float* scale, const float
     return STES_OK;
 }
 
-extern "C" int stes_se_fc(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-                          float* hidden, float* gate, int N, int C, int R, void* stream) {
-    STES_CHECK(pooled && w1 && b1 && w2 && b2 && hidden && gate, STES_ERR_ARG, "stes_se_fc: null pointer");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(TPB), (size_t)(C + R) * sizeof(float), S(stream), pooled, w1, b1, w2, b2, hidden, gate, C, R);
-    STES_LAUNCH_CHECK();
-    return STES_OK;
-}
-
-extern "C" int stes_se_fc_bwd(const float* dgate_raw, const float* gate, const float* hidden, const float* w1, const float* w2,
-                              float* dpre2, float* dpre1, float* dpool, float inv_hw, int N, int C, int R, void* stream) {
-    STES_CHECK(dgate_raw && gate && hidden && w1 && w2 && dpre2 && dpre1 && dpool, STES_ERR_ARG, "stes_se_fc_bwd: null pointer");
-    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(TPB), (size_t)(C + R) * sizeof(float), S(stream), dgate_raw, gate, hidden, w1, w2,
-                       dpre2, dpre1, dpool, inv_hw, C, R);
-    STES_LAUNCH_CHECK();
-    return STES_OK;
-}
-
-extern "C" int stes_f32_outer(const float* P, const float* Q, float* dW, float* db, int N, int n1, int n2, void* stream) {
-    STES_CHECK(P && Q && dW && N > 0, STES_ERR_ARG, "stes_f32_outer: null pointer");
-    hipLaunchKernelGGL(f32_outer_kernel, dim3(stes_div_up(n1, 16), stes_div_up(n2, 16)), dim3(TPB), 0, S(stream), P, Q, dW, db, N, n1, n2);
+extern "C" int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream) {
+    STES_CHECK(d && g && out && n > 0, STES_ERR_ARG, "stes_sigmoid_bwd: bad argument");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(stes_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d, g, (bf16*)out, (long)n);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

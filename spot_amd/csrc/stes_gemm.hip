@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
 #pragma unroll
         for (int r = 0; r < 4; ++r) { csum[i][r] = 0.f; csq[i][r] = 0.f; }
     const bool stats = p.col_sum != nullptr;
+    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
 
     for (int mt = slot; mt < m_tiles; mt += m_slots) {
         const long m0 = (long)mt * BM;
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] + bias[r];
+                    v[r] = acc[i][j][r] * out_scale + bias[r];
                     if (p.act == 1) v[r] = fmaxf(v[r], 0.f);
+                    else if (p.act == 2) v[r] = 1.f / (1.f + __expf(-v[r]));
                 }
                 if (p.relu_mask) {
                     const bf16* mk = (const bf16*)p.relu_mask + m * p.ldmask + nb;
@@ -253,6 +255,217 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         for (int t = tid; t < 2 * BN; t += 256) {
             const int which = t / BN, nl = t - which * BN;
             if (n0 + nl < N) atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[which * BN + nl] + red[(2 + which) * BN + nl]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ streaming GEMM for small K, N (weights resident in LDS)
+// The tall-and-skinny layers (K <= 320, column slice NB <= 160) are bound by HBM, not by MFMA.  Here the weight slice
+// [NB][K] sits in LDS for the workgroup's lifetime and every wave streams its own 32-row tiles with no workgroup barrier:
+// A fragments go global -> registers in MFMA operand layout (lane (fr,fq): row fr, k = 8fq..8fq+7: one 16-byte load), four
+// k-steps ahead of their use; the BatchNorm/ReLU/gate prologue runs in registers.  The output tile is staged through a
+// wave-private LDS buffer so that it leaves as whole rows (1 KiB per store instruction) and so that the BatchNorm
+// statistics of the rounded output cost 16 registers per lane (a lane always reads back the same 8 columns).
+template <int NI, int WAVES, bool GATE>   // NB = 16*NI columns per workgroup
+__global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
+                                                                 RowDivs dv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NB = NI * 16, D = 4;
+    constexpr int CPR = NB / 8;                 // 16-byte chunks per output row
+    constexpr int RPP = 64 / CPR;               // output rows per store pass of a wave
+    constexpr int SRS = NB * 2 + 16;            // staging row stride (bytes)
+    const int K = p.K, N = p.N, nk = K >> 5;
+    const long M = p.M;
+    const int RS = 2 * K + 32;                  // weight row stride (bytes): (RS/16) % 4 == 2 keeps the b128 fragment reads conflict-free
+    unsigned char* wl = smem;
+    unsigned char* stage = smem + NB * RS + (threadIdx.x >> 6) * 16 * SRS;
+    float* sc_s = reinterpret_cast<float*>(smem + NB * RS + WAVES * 16 * SRS);
+    float* sh_s = sc_s + K;
+    float* red = sh_s + K;                      // [2][NB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int slice = idx % n_slices;
+    const int slot = (idx / n_slices) * 8 + xcd;
+    const int n0 = slice * NB;
+    const bf16* __restrict__ A = (const bf16*)p.A;
+    const bf16* __restrict__ A0 = (const bf16*)p.A0;
+    const bool has_affine = p.a_scale != nullptr;
+    const bool stats = p.col_sum != nullptr;
+    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
+
+    {   // weight slice, prologue constants, statistics scratch
+        const bf16* __restrict__ W = (const bf16*)p.W;
+        const int kch = K >> 3;
+        for (int c = tid; c < NB * kch; c += WAVES * 64) {
+            const int r = c / kch, kc = c - r * kch;
+            const bf16x8 v = (n0 + r < N) ? *reinterpret_cast<const bf16x8*>(W + (long)(n0 + r) * p.ldw + kc * 8) : zero8();
+            *reinterpret_cast<bf16x8*>(wl + r * RS + kc * 16) = v;
+        }
+        if (has_affine) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.a_scale[k]; sh_s[k] = p.a_shift[k]; }
+        for (int k = tid; k < 2 * NB; k += WAVES * 64) red[k] = 0.f;
+    }
+    __syncthreads();
+    if (slot >= m_slots) return;
+
+    // ---- cursors: the fetch cursor runs D k-steps ahead of the compute cursor
+    const long tstride = (long)m_slots * WAVES;
+    long f_tile = (long)slot * WAVES + wave, c_tile = f_tile;
+    int f_ks = 0, c_ks = 0;
+    const bf16* f_a[2]; const bf16* f_a0[2];
+    auto f_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long m = f_tile * 32 + j * 16 + fr;
+            f_a[j] = nullptr; f_a0[j] = nullptr;
+            if (f_tile < row_tiles && m < M) {
+                long src = m;
+                if (p.map_stride > 1) {
+                    uint32_t n, rem, ho, wo;
+                    fdivmod((uint32_t)m, dv.hw, n, rem);
+                    fdivmod(rem, dv.wo, ho, wo);
+                    src = ((long)n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                }
+                f_a[j] = A + src * p.lda;
+                if (A0) f_a0[j] = A0 + src * p.lda0;
+            }
+        }
+    };
+    const float* c_gate[2] = {nullptr, nullptr};
+    auto c_rows = [&]() {
+        if (GATE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                long m = c_tile * 32 + j * 16 + fr;
+                if (m >= M) m = M - 1;
+                c_gate[j] = p.a_gate + (long)fdiv((uint32_t)m, dv.gate) * K;
+            }
+        }
+    };
+    bf16x8 ring[D][2];
+    auto fetch = [&](int d) {
+        const int k = f_ks * 32 + fq * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (f_a[j] != nullptr) ring[d][j] = *reinterpret_cast<const bf16x8*>((k < p.k0 ? f_a0[j] : f_a[j]) + k);
+            else ring[d][j] = zero8();
+        }
+        if (++f_ks == nk) { f_ks = 0; f_tile += tstride; f_rows(); }
+    };
+
+    f32x4 acc[NI][2];
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    const int o_chunk = lane % CPR, o_rsub = lane / CPR;        // store phase: this lane's 8 columns and row phase
+    const bool o_active = o_rsub < RPP;
+
+    f_rows(); c_rows();
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d);
+
+    while (c_tile < row_tiles) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (c_tile >= row_tiles) break;
+            if (c_ks == 0) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            }
+            // ---- prologue on the two A fragments of this k-step
+            bf16x8 fb[2] = {ring[d][0], ring[d][1]};
+            const int k = c_ks * 32 + fq * 8;
+            if (has_affine || GATE) {
+                float s[8], b[8];
+                if (has_affine) { load8f(sc_s + k, s); load8f(sh_s + k, b); }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float f[8];
+                    unpack8(fb[j], f);
+                    if (has_affine) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = f[e] * s[e] + b[e];
+                        if (p.a_relu) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                        }
+                    }
+                    if (GATE) {
+                        float g[8];
+                        load8f(c_gate[j] + k, g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] *= g[e];
+                    }
+                    fb[j] = pack8(f);
+                }
+            }
+            fetch(d);                               // refill this slot for the step D ahead
+            // ---- MFMA: D[n][m] += W[n][k] A[m][k]
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + (i * 16 + fr) * RS + k * 2);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fb[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fb[1], acc[i][1], 0, 0, 0);
+            }
+            if (++c_ks < nk) continue;
+            // ---- tile done: bias / activation in registers, then through the staging buffer, 16 rows at a time
+            c_ks = 0;
+            const long m_base = c_tile * 32;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int nb = n0 + i * 16 + fq * 4;
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r] * out_scale + (p.bias ? p.bias[nb + r] : 0.f);
+                        if (p.act == 1) v = fmaxf(v, 0.f);
+                        else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
+                        o[r] = (bf16)v;
+                    }
+                    *reinterpret_cast<bf16x4*>(stage + fr * SRS + (i * 16 + fq * 4) * 2) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (o_active) {
+                    const int col = n0 + o_chunk * 8;
+#pragma unroll
+                    for (int rr = 0; rr < (16 + RPP - 1) / RPP; ++rr) {
+                        const int row = rr * RPP + o_rsub;
+                        const long m = m_base + j * 16 + row;
+                        if (row < 16 && m < M) {
+                            bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * SRS + o_chunk * 16);
+                            if (p.relu_mask) {
+                                const bf16x8 mk = *reinterpret_cast<const bf16x8*>((const bf16*)p.relu_mask + m * p.ldmask + col);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (!((float)mk[e] > 0.f)) v[e] = (bf16)0.f;
+                            }
+                            bf16* dst = (col < p.n_split) ? (bf16*)p.C0 + m * p.ldc0 + col : (bf16*)p.C + m * p.ldc + col;
+                            *reinterpret_cast<bf16x8*>(dst) = v;
+                            if (stats) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ssum[e] += f; ssq[e] += f * f; }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            c_tile += tstride;
+            c_rows();
+        }
+    }
+    if (stats) {
+        if (o_active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(&red[o_chunk * 8 + e], ssum[e]); atomicAdd(&red[NB + o_chunk * 8 + e], ssq[e]); }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * NB; t += WAVES * 64) {
+            const int which = t / NB, nl = t - which * NB;
+            atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[t]);
         }
     }
 }
@@ -437,6 +650,49 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     STES_CHECK((a->col_sum == nullptr) == (a->col_sumsq == nullptr), STES_ERR_ARG, "stes_gemm: stats pointers");
     STES_CHECK(!(a->col_sum && a->c_f32), STES_ERR_ARG, "stes_gemm: stats need bf16 output");
     STES_CHECK(a->n_split == 0 || (a->C0 && !a->c_f32 && a->n_split % 4 == 0 && a->ldc0 % 4 == 0 && a->ldc0 >= a->n_split), STES_ERR_ARG, "stes_gemm: split output");
+    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_gemm: more than 2^31 rows");
+    RowDivs dv;
+    dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
+    dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
+    dv.gate = make_fastdiv(a->a_gate ? a->gate_group : 1);
+    // tall-and-skinny bf16 layers with small K and N: weights resident in LDS, rows streamed (gemm_stream_kernel)
+    {
+        int nb = 0;
+        if (a->N == 32 || a->N == 64 || a->N == 128 || a->N == 160) nb = a->N;
+        else if (a->N == 320) nb = 160;
+        const bool fits = nb > 0 && a->K % 32 == 0 && a->K <= 320 && !a->c_f32 && a->M >= 8192 && a->ldc % 8 == 0 &&
+                          (a->k0 == 0 || a->k0 % 8 == 0) && (a->n_split == 0 || (a->n_split % 8 == 0 && a->ldc0 % 8 == 0)) &&
+                          (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0));
+        if (fits) {
+            const int ni = nb / 16, waves = nb >= 128 ? 8 : 4;
+            const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) + (size_t)(2 * a->K + 2 * nb) * sizeof(float);
+            const int n_slices = a->N / nb;
+            const int row_tiles = stes_div_up(a->M, 32);
+            int per_cu = (int)((160 * 1024) / lds);
+            if (per_cu > 32 / waves) per_cu = 32 / waves;
+            if (per_cu < 1) per_cu = 1;
+            int m_slots = stes_div_up(row_tiles, waves);
+            const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;
+            if (m_slots > cap) m_slots = cap;
+            const int grid = stes_div_up(m_slots, 8) * n_slices * 8;
+            static bool attr_done = false;
+#define STREAM_CASE(NI_, W_, G_)                                                                                                   \
+    do {                                                                                                                           \
+        if (!attr_done) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI_, W_, G_>),                \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        hipLaunchKernelGGL((gemm_stream_kernel<NI_, W_, G_>), dim3(grid), dim3(W_ * 64), lds, (hipStream_t)stream, *a, row_tiles,   \
+                           n_slices, m_slots, dv);                                                                                 \
+    } while (0)
+            const bool g = a->a_gate != nullptr;
+            if (ni == 2) STREAM_CASE(2, 4, false);
+            else if (ni == 4) { if (g) STREAM_CASE(4, 4, true); else STREAM_CASE(4, 4, false); }
+            else if (ni == 8) { if (g) STREAM_CASE(8, 8, true); else STREAM_CASE(8, 8, false); }
+            else { if (g) STREAM_CASE(10, 8, true); else STREAM_CASE(10, 8, false); }
+#undef STREAM_CASE
+            STES_LAUNCH_CHECK();
+            return STES_OK;
+        }
+    }
     const int m_tiles = stes_div_up(a->M, BM);
     const bool wide = a->N > 64;
     const int bn = wide ? 128 : 64;
@@ -446,11 +702,6 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     if (m_slots > cap) m_slots = cap;
     const int slot_groups = stes_div_up(m_slots, 8);
     const int grid = slot_groups * n_tiles * 8;
-    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_gemm: more than 2^31 rows");
-    RowDivs dv;
-    dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
-    dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
-    dv.gate = make_fastdiv(a->a_gate ? a->gate_group : 1);
     if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
     else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
     STES_LAUNCH_CHECK();

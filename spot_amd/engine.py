@@ -100,6 +100,9 @@ class Block:
         eng.packs.append((self.w2, self.wp2_f, self.wp2_d, G))
         self.se = blk.se
         self.rd = blk.se.fc1.out_channels
+        if self.rd % 8:
+            raise NotImplementedError("squeeze-excite reduction width must be a multiple of 8")
+        self.se1, self.se2 = Linear(eng, blk.se.fc1.weight), Linear(eng, blk.se.fc2.weight)
         self.down = isinstance(blk.downsample, ConvBnAct)
         if self.down:
             self.ld = Linear(eng, blk.downsample.conv.weight)
@@ -130,8 +133,8 @@ class Block:
         self.c1 = a(nm + ".c1", self.Mi * self.cmid, BF)
         self.c2 = a(nm + ".c2", self.Mo * self.cmid, BF)
         self.c3 = a(nm + ".c3", self.Mo * self.cout, BF)
-        self.pooled = a(nm + ".pooled", N * self.cmid, F32)
-        self.hidden = a(nm + ".hidden", N * self.rd, F32)
+        self.pooled = a(nm + ".pooled", N * self.cmid, BF)
+        self.hidden = a(nm + ".hidden", N * self.rd, BF)
         self.segate = a(nm + ".segate", N * self.cmid, F32)
         if self.down:
             self.sc = a(nm + ".sc", self.Mo * self.cout, BF)
@@ -166,10 +169,11 @@ class Block:
                  p(s2[0]) if s2 else None, p(s2[1]) if s2 else None, self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
         self.bn2.finalize(Mo, train)
         HWo = self.Ho * self.Wo
-        lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, p(self.pooled), None, self.N, HWo, cmid, 1.0 / HWo)
+        # squeeze-excite: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid, the two FCs as MFMA GEMMs over the frames
+        lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, None, p(self.pooled), self.N, HWo, cmid, 1.0 / HWo)
         se = self.se
-        lib.call("stes_se_fc", p(self.pooled), p(se.fc1.weight), p(se.fc1.bias), p(se.fc2.weight), p(se.fc2.bias), p(self.hidden),
-                 p(self.segate), self.N, cmid, self.rd)
+        lib.gemm(self.pooled, self.se1.w_bf, self.hidden, self.N, self.rd, cmid, bias=se.fc1.bias, act=1)
+        lib.gemm(self.hidden, self.se2.w_bf, self.segate, self.N, cmid, self.rd, bias=se.fc2.bias, act=2)
         lib.gemm(self.c2, self.l3.w_bf, self.c3, Mo, cout, cmid, scale=self.bn2.scale, shift=self.bn2.shift, relu=True,
                  gate=self.segate, gate_group=HWo, stats=st(self.bn3))
         self.bn3.finalize(Mo, train)
@@ -207,12 +211,13 @@ class Block:
         # --- squeeze-excite backward
         dgate = sc("se.dgate", self.N * cmid, F32)
         lib.call("stes_chan_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(dgate), None, self.N, HWo, cmid, 1.0)
-        dpre2, dpre1, dpool = sc("se.dpre2", self.N * cmid, F32), sc("se.dpre1", self.N * self.rd, F32), sc("se.dpool", self.N * cmid, F32)
-        se = self.se
-        lib.call("stes_se_fc_bwd", p(dgate), p(self.segate), p(self.hidden), p(se.fc1.weight), p(se.fc2.weight), p(dpre2), p(dpre1),
-                 p(dpool), 1.0 / HWo, self.N, cmid, self.rd)
-        lib.call("stes_f32_outer", p(dpre2), p(self.hidden), p(g(se.fc2.weight)), p(g(se.fc2.bias)), self.N, cmid, self.rd)
-        lib.call("stes_f32_outer", p(dpre1), p(self.pooled), p(g(se.fc1.weight)), p(g(se.fc1.bias)), self.N, self.rd, cmid)
+        dpre2, dpre1, dpool = sc("se.dpre2", self.N * cmid), sc("se.dpre1", self.N * self.rd), sc("se.dpool", self.N * cmid, F32)
+        se, rd = self.se, self.rd
+        lib.call("stes_sigmoid_bwd", p(dgate), p(self.segate), p(dpre2), self.N * cmid)
+        lib.gemm(dpre2, self.se2.wT_bf, dpre1, self.N, rd, cmid, ldw=self.se2.Np, relu_mask=self.hidden, ldmask=rd)
+        lib.gemm(dpre1, self.se1.wT_bf, dpool, self.N, cmid, rd, ldw=self.se1.Np, out_scale=1.0 / HWo)
+        lib.wgrad(dpre2, self.hidden, g(se.fc2.weight), self.N, cmid, rd, dbias=g(se.fc2.bias))
+        lib.wgrad(dpre1, self.pooled, g(se.fc1.weight), self.N, rd, cmid, dbias=g(se.fc1.bias))
         # --- conv2.bn backward: dY2 = (dA3*gate + dpool) * [bn2(c2) > 0]
         kw2 = dict(mul=self.segate, add=dpool, group=HWo, act=(self.c2, bn2.scale, bn2.shift))
         lib.bn_bwd_reduce(dA3, self.c2, Mo, cmid, [bn2.s_dy, bn2.s_dyr], **kw2)

@@ -37,7 +37,7 @@ GemmArgs = _struct("GemmArgs", [
     ("col_sum", _P), ("col_sumsq", _P),
     ("relu_mask", _P), ("ldmask", _I64),
     ("C0", _P), ("ldc0", _I64), ("n_split", _I32),
-    ("M", _I64), ("N", _I32), ("K", _I32)])
+    ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -69,9 +69,7 @@ _SIGS = {
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
-    "stes_se_fc": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
-    "stes_se_fc_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
-    "stes_f32_outer": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
     "stes_bn_bwd_reduce": [_P, _P],
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
     "stes_bn_bwd_apply": [_P, _P],
@@ -156,7 +154,7 @@ def _gemm_work(a, out_bytes):
 # ---------------------------------------------------------------- struct-argument entry points
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
-         bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0):
+         bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0):
     """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
@@ -172,7 +170,7 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
         a.col_sum, a.col_sumsq = ptr(stats[0]), ptr(stats[1])
     a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
     a.C0, a.ldc0, a.n_split = ptr(C0), ldc0, n_split
-    a.M, a.N, a.K = M, N, K
+    a.M, a.N, a.K, a.out_scale = M, N, K, out_scale
     if TIMING is not None and N > 64:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

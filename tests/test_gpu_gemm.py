@@ -61,6 +61,64 @@ def test_gemm_prologue_stats_compact_and_rowmap():
     torch.testing.assert_close(s2.cpu(), (cb * cb).sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("N,K,mode", [(32, 32, "plain"), (64, 32, "rowmap"), (32, 64, "mask"), (64, 64, "gate"), (128, 64, "compact"),
+                                      (128, 128, "gate"), (64, 128, "mask"), (320, 128, "plain"), (320, 320, "gate"), (128, 320, "mask"),
+                                      (160, 96, "compact")])
+def test_gemm_streaming_path(N, K, mode):
+    """Shapes that take the weights-resident streaming kernel (K <= 320, N in {32,64,128,160,320}, M >= 8192), with each
+    fused option it serves: BN+ReLU(+SE gate) prologue and output statistics, compact first columns, stride-2 row map,
+    ReLU mask + split output + bias."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(N * 7 + K)
+    n_img, Ho, Wo = 3, 53, 52
+    M = n_img * Ho * Wo                                   # 8268 rows, ragged last tile
+    W = _bf(N, K, g=g, scale=K ** -0.5)
+    Cout = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    kw, ref_a = {}, None
+    if mode == "rowmap":
+        Hi, Wi = 2 * Ho, 2 * Wo
+        X = _bf(n_img * Hi * Wi, K, g=g)
+        ref_a = X.float().view(n_img, Hi, Wi, K)[:, ::2, ::2].reshape(M, K)
+        kw = dict(rowmap=(2, Ho, Wo, Hi, Wi))
+    else:
+        X = _bf(M, K, g=g)
+        ref_a = X.float()
+    if mode == "compact":
+        fold = 16
+        G = _bf(M, fold, g=g)
+        ref_a = torch.cat([G.float(), ref_a[:, fold:]], 1)
+        kw.update(A0=dev(G), lda0=fold, k0=fold)
+    if mode in ("gate", "compact", "rowmap"):
+        scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+        ref_a = torch.relu(ref_a * scale + shift)
+        kw.update(scale=dev(scale), shift=dev(shift), relu=True)
+    if mode == "gate":
+        gate = torch.rand(n_img, K, generator=g)
+        ref_a = (ref_a.view(n_img, Ho * Wo, K) * gate[:, None]).reshape(M, K)
+        kw.update(gate=dev(gate), gate_group=Ho * Wo)
+    ref = ref_a.to(torch.bfloat16).float() @ W.float().t()
+    s1 = torch.zeros(N, device="cuda"); s2 = torch.zeros(N, device="cuda")
+    C0 = None
+    if mode == "mask":
+        bias = torch.randn(N, generator=g)
+        mask = _bf(M, N, g=g)
+        ref = (0.5 * ref + bias) * (mask.float() > 0)
+        C0 = torch.full((M, 16), 5.0, dtype=torch.bfloat16, device="cuda")
+        kw.update(bias=dev(bias), relu_mask=dev(mask), ldmask=N, C0=C0, ldc0=16, n_split=16, out_scale=0.5)
+    else:
+        kw.update(stats=(s1, s2))
+    lib.gemm(dev(X), dev(W), Cout, M, N, K, **kw)
+    torch.cuda.synchronize()
+    got = Cout.float().cpu()
+    if mode == "mask":
+        assert bool((got[:, :16] == 7.0).all())            # the first columns went to the compact tensor
+        got[:, :16] = C0.float().cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+    if mode != "mask":
+        torch.testing.assert_close(s1.cpu(), got.sum(0), rtol=1e-3, atol=5e-2)
+        torch.testing.assert_close(s2.cpu(), (got * got).sum(0), rtol=1e-3, atol=5e-2)
+
+
 @pytest.mark.parametrize("M,N1,N2", [(256, 64, 32), (1000, 128, 64), (4099, 320, 320), (2048, 768, 768), (500, 7, 1536), (3000, 64, 64)])
 def test_wgrad(M, N1, N2):
     from spot_amd import lib
