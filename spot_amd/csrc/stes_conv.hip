@@ -129,6 +129,175 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ forward / stride-1 input gradient, LDS row ring
+// Workgroup = (image, 64-channel block = 4 groups, one per wave).  It walks down the image keeping the input rows it
+// needs in an LDS ring (pixel stride 160 bytes: 128 of data + 32 of padding, which spreads the fragment reads over the
+// banks), so every input element is fetched from memory once and BatchNorm + ReLU is applied once, at the store into LDS.
+// The next step's rows travel global -> registers while the current rows are convolved.  Results are staged in LDS and
+// leave as whole 128-byte pixel rows; a thread always stores the same 8 channels, so the output statistics take 16
+// registers.
+struct RowsGeom {
+    int N, Hs, Ws, Hd, Wd, C;
+    int RS, NR;                        // output rows per step, ring rows
+    FastDiv fd_wd, fd_px8;             // Wd; 8 * Ws (16-byte chunks per input row of the channel block)
+};
+constexpr int PSB = 160;               // LDS bytes per pixel
+constexpr int CONV_MAXI = 7;           // staged 16-byte chunks per thread per step
+
+template <int STRIDE, bool FLIP>
+__global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
+                                                            bf16* __restrict__ dst, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* col_sum, float* col_sumsq,
+                                                            RowsGeom gm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int ncb = gm.C >> 6;
+    const int cb = blockIdx.x % ncb, n_first = blockIdx.x / ncb, n_step = gridDim.x / ncb;   // gridDim.x is a multiple of ncb
+    const int g = cb * 4 + wave;
+    const int Hs = gm.Hs, Ws = gm.Ws, Hd = gm.Hd, Wd = gm.Wd, C = gm.C, RS = gm.RS, NR = gm.NR;
+    const int ROWB = (Ws + 2) * PSB;
+    constexpr int NEW = STRIDE;                       // new input rows per output row
+    unsigned char* ring = smem;
+    unsigned char* stage = smem + NR * ROWB;          // [RS*Wd][128 B]
+    float* red = reinterpret_cast<float*>(stage + RS * Wd * 128);   // [2][64]
+
+    bf16x8 wf[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(wp + (((long)g * 5 + s) * 64 + lane) * 8);
+    const bool affine = scale != nullptr;
+    const bool stats = col_sum != nullptr;
+    const int chunk = tid & 7;                        // this thread's 8 channels in the staging / store phases
+    float sc[8], sh[8];
+    if (affine) { load8f(scale + cb * 64 + chunk * 8, sc); load8f(shift + cb * 64 + chunk * 8, sh); }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    // zero the left / right halo columns of every ring row once; they are never written again
+    for (int i = tid; i < NR * 2 * 8; i += 256) {
+        const int r = i >> 4, side = (i >> 3) & 1, ch = i & 7;
+        *reinterpret_cast<bf16x8*>(ring + r * ROWB + (side ? (Ws + 1) * PSB : 0) + ch * 16) = zero8();
+    }
+    if (tid < 128) red[tid] = 0.f;
+
+    const bf16* img = nullptr;
+    bf16x8 regs[CONV_MAXI];
+    // rows [first, first + count) of the input -> registers; rows outside the image are zero rows
+    auto fetch = [&](int first, int count) {
+        const int items = count * Ws * 8;
+#pragma unroll
+        for (int k = 0; k < CONV_MAXI; ++k) {
+            const int i = tid + k * 256;
+            regs[k] = zero8();
+            if (i < items) {
+                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
+                const int px = (i - (int)r * Ws * 8) >> 3, ir = first + (int)r;
+                if (ir >= 0 && ir < Hs) regs[k] = *reinterpret_cast<const bf16x8*>(img + ((long)ir * Ws + px) * C);
+            }
+        }
+    };
+    auto commit = [&](int first, int count) {
+        const int items = count * Ws * 8;
+#pragma unroll
+        for (int k = 0; k < CONV_MAXI; ++k) {
+            const int i = tid + k * 256;
+            if (i < items) {
+                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
+                const int px = (i - (int)r * Ws * 8) >> 3, ir = first + (int)r;
+                bf16x8 v = regs[k];
+                if (affine && ir >= 0 && ir < Hs) {
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f);
+                    v = pack8(f);
+                }
+                *reinterpret_cast<bf16x8*>(ring + ((ir + 1) % NR) * ROWB + (px + 1) * PSB + chunk * 16) = v;
+            }
+        }
+    };
+
+    // rows before the first step's new rows: stride 1 needs {-1, 0}, stride 2 needs {-1}
+    const int base0 = STRIDE == 1 ? 1 : 0;
+    for (int n = n_first; n < gm.N; n += n_step) {       // images of this workgroup; statistics stay in registers
+    img = src + (long)n * Hs * Ws * C + cb * 64 + chunk * 8;
+    __syncthreads();                                     // the previous image's ring and staging are no longer read
+    fetch(-1, base0 + 1);
+    commit(-1, base0 + 1);
+    fetch(base0, RS * NEW);
+    const int nsteps = (Hd + RS - 1) / RS;
+    const int P_full = RS * Wd;
+    for (int st = 0; st < nsteps; ++st) {
+        const int first_new = base0 + st * RS * NEW;
+        commit(first_new, RS * NEW);
+        __syncthreads();
+        if (st + 1 < nsteps) fetch(first_new + RS * NEW, RS * NEW);
+        const int row0 = st * RS;
+        const int rows_here = (row0 + RS <= Hd) ? RS : Hd - row0;
+        const int P = rows_here * Wd;
+        const int nfrag = (P + 15) >> 4;
+        for (int f = 0; f < nfrag; ++f) {
+            int pi = f * 16 + p;
+            const bool valid = pi < P;
+            if (!valid) pi = P - 1;
+            uint32_t orow, ocol;
+            fdivmod((uint32_t)pi, gm.fd_wd, orow, ocol);
+            const int arow = row0 + (int)orow;            // absolute output row
+            // ring slot of the input row under tap row kh: forward reads row arow*STRIDE + kh - 1, the flipped (input
+            // gradient) form reads row arow + 1 - kh
+            int rb[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ir = FLIP ? arow + 1 - kh : arow * STRIDE + kh - 1;
+                rb[kh] = ((ir + 1) % NR) * ROWB;
+            }
+            const int colb = ((int)ocol * STRIDE) * PSB + wave * 32 + (q & 1) * 16;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                // this lane's tap of k-step s: 2s + (q >> 1)
+                const int t0 = 2 * s, t1 = 2 * s + 1;
+                const int kh0 = t0 / 3, kw0 = t0 % 3, kh1 = t1 / 3, kw1 = t1 % 3;
+                bf16x8 frag = zero8();
+                if (q < 2) {
+                    const int cw = FLIP ? 2 - kw0 : kw0;
+                    frag = *reinterpret_cast<const bf16x8*>(ring + rb[kh0] + colb + cw * PSB);
+                } else if (t1 < 9) {
+                    const int cw = FLIP ? 2 - kw1 : kw1;
+                    frag = *reinterpret_cast<const bf16x8*>(ring + rb[kh1 < 3 ? kh1 : 0] + colb + cw * PSB);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], frag, acc, 0, 0, 0);
+            }
+            if (valid) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[r];
+                *reinterpret_cast<bf16x4*>(stage + pi * 128 + wave * 32 + q * 8) = o;
+            }
+        }
+        __syncthreads();
+        // staged pixels -> global, 128 contiguous bytes per pixel (fully contiguous when C == 64)
+        bf16* out = dst + ((long)(n * Hd + row0) * Wd) * C + cb * 64 + chunk * 8;
+        for (int px = tid >> 3; px < P; px += 32) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+            *reinterpret_cast<bf16x8*>(out + (long)px * C) = v;
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float fv = (float)v[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+            }
+        }
+        (void)P_full;
+    }
+    }
+    if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); }
+        __syncthreads();
+        if (tid < 128) atomicAdd((tid < 64 ? col_sum : col_sumsq) + cb * 64 + (tid & 63), red[tid]);
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 constexpr int TH = 4, TW = 8;                 // 32 output pixels per reduction step
 constexpr int MAX_HALO = 9 * 17;              // stride 2: (TH-1)*2+3 by (TW-1)*2+3
@@ -276,6 +445,66 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     STES_CHECK(stride == 1 || stride == 2, STES_ERR_ARG, "stes_conv3x3g: stride must be 1 or 2");
     STES_CHECK(Ho == (Hi + 2 - 3) / stride + 1 && Wo == (Wi + 2 - 3) / stride + 1, STES_ERR_ARG, "stes_conv3x3g: output size does not match");
     STES_CHECK((scale == nullptr) == (shift == nullptr) && (col_sum == nullptr) == (col_sumsq == nullptr), STES_ERR_ARG, "stes_conv3x3g: paired pointers");
+    if (mode == 0 || stride == 1) {
+        // LDS row-ring kernel when its ring + staging fit
+        RowsGeom rg;
+        rg.N = N; rg.C = C;
+        if (mode == 0) { rg.Hs = Hi; rg.Ws = Wi; rg.Hd = Ho; rg.Wd = Wo; }
+        else { rg.Hs = Ho; rg.Ws = Wo; rg.Hd = Hi; rg.Wd = Wi; }
+        const int st = mode == 0 ? stride : 1;
+        auto lds_of = [&](int rs) {
+            const int nr = st == 1 ? rs + 2 : 2 * rs + 1;
+            return (size_t)nr * (rg.Ws + 2) * PSB + (size_t)rs * rg.Wd * 128 + 128 * sizeof(float);
+        };
+        int cap = 196 / rg.Wd; if (cap < 1) cap = 1; if (cap > rg.Hd) cap = rg.Hd;
+        int best = 0, best_steps = 1 << 30;
+        for (int rs = cap; rs >= 1; --rs) {
+            if ((long)rs * st * rg.Ws * 8 > CONV_MAXI * 256 || lds_of(rs) > 72 * 1024) continue;
+            const int steps = stes_div_up(rg.Hd, rs);
+            if (steps < best_steps) { best_steps = steps; best = rs; }
+        }
+        if (best == 0 && (long)st * rg.Ws * 8 <= CONV_MAXI * 256 && lds_of(1) <= 150 * 1024) best = 1;
+        if (best > 0 && (long)N * (C / 64) < (1L << 31)) {
+            rg.RS = best; rg.NR = st == 1 ? best + 2 : 2 * best + 1;
+            rg.fd_wd = make_fastdiv(rg.Wd); rg.fd_px8 = make_fastdiv(rg.Ws * 8);
+            const size_t lds = lds_of(best);
+            const int ncb = C / 64;
+            static const bool big_lds = [] {
+                bool ok = true;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                return ok;
+            }();
+            // as many workgroups as are resident at once: every further one would only add device-scope statistics
+            // atomics, which serialise at the end of the launch (residency cached per kernel form and LDS size)
+            const int form = mode == 1 ? 2 : (stride == 1 ? 0 : 1);
+            static size_t seen_lds[3][8];
+            static int seen_val[3][8], n_seen[3] = {0, 0, 0};
+            int resident = 0;
+            for (int i = 0; i < n_seen[form]; ++i) if (seen_lds[form][i] == lds) resident = seen_val[form][i];
+            if (resident == 0) {
+                hipError_t e = hipSuccess;
+                if (form == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, conv3x3g_rows_kernel<1, true>, 256, lds);
+                else if (form == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, conv3x3g_rows_kernel<1, false>, 256, lds);
+                else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, conv3x3g_rows_kernel<2, false>, 256, lds);
+                if (e != hipSuccess || resident < 1) resident = 1;
+                if (n_seen[form] < 8) { seen_lds[form][n_seen[form]] = lds; seen_val[form][n_seen[form]] = resident; ++n_seen[form]; }
+            }
+            int per = 256 * resident / ncb; if (per < 1) per = 1; if (per > N) per = N;
+            const dim3 grid(per * ncb);
+            if (big_lds || lds <= 64 * 1024) {
+#define ROWS_LAUNCH(ST, FL) hipLaunchKernelGGL((conv3x3g_rows_kernel<ST, FL>), grid, dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, \
+        (bf16*)dst, scale, shift, col_sum, col_sumsq, rg)
+                if (mode == 1) ROWS_LAUNCH(1, true);
+                else if (stride == 1) ROWS_LAUNCH(1, false);
+                else ROWS_LAUNCH(2, false);
+#undef ROWS_LAUNCH
+                STES_LAUNCH_CHECK();
+                return STES_OK;
+            }
+        }
+    }
     ConvGeom gm;
     gm.N = N; gm.stride = stride; gm.C = C; gm.G = C / 16;
     if (mode == 0) { gm.Hs = Hi; gm.Ws = Wi; gm.Hd = Ho; gm.Wd = Wo; }

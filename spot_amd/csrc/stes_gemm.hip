@@ -637,6 +637,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     }
 }
 
+// Workgroups of one streaming-GEMM instantiation resident per CU at a given dynamic LDS size (cached: queried once per size).
+template <int NI, int WAVES, bool GATE>
+static int stream_residency(size_t lds) {
+    static bool attr_done = false;
+    static size_t seen[8];
+    static int val[8];
+    static int n_seen = 0;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, GATE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    for (int i = 0; i < n_seen; ++i) if (seen[i] == lds) return val[i];
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_kernel<NI, WAVES, GATE>, WAVES * 64, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (n_seen < 8) { seen[n_seen] = lds; val[n_seen] = per_cu; ++n_seen; }
+    return per_cu;
+}
+
 }  // namespace
 
 extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
@@ -668,18 +688,14 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
             const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) + (size_t)(2 * a->K + 2 * nb) * sizeof(float);
             const int n_slices = a->N / nb;
             const int row_tiles = stes_div_up(a->M, 32);
-            int per_cu = (int)((160 * 1024) / lds);
-            if (per_cu > 32 / waves) per_cu = 32 / waves;
-            if (per_cu < 1) per_cu = 1;
-            int m_slots = stes_div_up(row_tiles, waves);
-            const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;
-            if (m_slots > cap) m_slots = cap;
-            const int grid = stes_div_up(m_slots, 8) * n_slices * 8;
-            static bool attr_done = false;
+            int per_cu = 1;
 #define STREAM_CASE(NI_, W_, G_)                                                                                                   \
     do {                                                                                                                           \
-        if (!attr_done) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI_, W_, G_>),                \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        per_cu = stream_residency<NI_, W_, G_>(lds);                                                                               \
+        int m_slots = stes_div_up(row_tiles, W_);                                                                                  \
+        const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;                                                 \
+        if (m_slots > cap) m_slots = cap;                                                                                          \
+        const int grid = stes_div_up(m_slots, 8) * n_slices * 8;                                                                   \
         hipLaunchKernelGGL((gemm_stream_kernel<NI_, W_, G_>), dim3(grid), dim3(W_ * 64), lds, (hipStream_t)stream, *a, row_tiles,   \
                            n_slices, m_slots, dv);                                                                                 \
     } while (0)

@@ -43,7 +43,8 @@ def close(a, b, rtol=1e-2, atol=1e-2):
     torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("stride,H,W,C", [(1, 14, 14, 64), (2, 16, 12, 64), (1, 7, 7, 128), (2, 28, 28, 128), (2, 9, 7, 64)])
+@pytest.mark.parametrize("stride,H,W,C", [(1, 14, 14, 64), (2, 16, 12, 64), (1, 7, 7, 128), (2, 28, 28, 128), (2, 9, 7, 64), (1, 28, 28, 128),
+                                             (2, 56, 56, 64), (1, 30, 50, 64), (2, 25, 13, 320), (1, 13, 25, 192), (2, 40, 199, 64)])
 def test_conv3x3g(stride, H, W, C):
     from spot_amd import lib
     g = torch.Generator().manual_seed(3)
