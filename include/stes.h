@@ -135,10 +135,11 @@ int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_
 /* ---------------------------------------------------- grouped 3x3 convolution ----
  * timm regnety_008 conv2: 3x3, padding 1, stride 1|2, groups = C/16, no bias.  in/out NHWC bf16.
  * Weights are re-packed from the checkpoint layout [C][16][3][3] fp32 into MFMA fragment order
- * by stes_pack_conv3x3g (one buffer for forward, one for the input gradient; G*5*512 bf16 each).
+ * by stes_pack_conv3x3g (one buffer for forward, one for the input gradient; G*5*512 bf16 each; the
+ * input-gradient order depends on the stride: stride 2 groups the taps by output-pixel parity).
  * forward applies relu(in_scale*x + in_shift) (the previous BatchNorm+ReLU) while loading and
  * accumulates the output's per-channel sum / sum of squares.                              */
-int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int G, void* stream);
+int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int G, int stride, void* stream);
 int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
                       const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
                       int stride, int C, void* stream);

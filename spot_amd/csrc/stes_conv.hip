@@ -16,18 +16,22 @@ namespace {
 // ------------------------------------------------------------------ weight packing
 // w [G*16][16][3][3] fp32 ->  fwd [G][5][64][8]: lane(i=co,q): tap=2s+(q>>1), ci=(q&1)*8+j
 //                             dgr [G][5][64][8]: lane(i=ci,q): tap=2s+(q>>1), co=(q&1)*8+j
-__global__ void pack_conv3x3g_kernel(const float* __restrict__ w, bf16* __restrict__ fwd, bf16* __restrict__ dgr, int G) {
+// stride-2 input gradient: taps grouped by output-pixel parity class (row parity, column parity); k-step s pairs the taps
+//   s=0 (even,even): (1,1), -      s=1 (even,odd): (1,0),(1,2)      s=2 (odd,even): (0,1),(2,1)
+//   s=3,4 (odd,odd): (0,0),(0,2) and (2,0),(2,2)           (tap index kh*3+kw; the first of a pair reads source index + 1)
+__constant__ int kParityTaps[5][2] = {{4, -1}, {3, 5}, {1, 7}, {0, 2}, {6, 8}};
+
+__global__ void pack_conv3x3g_kernel(const float* __restrict__ w, bf16* __restrict__ fwd, bf16* __restrict__ dgr, int G, int stride) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = G * 5 * 64 * 8;
     if (idx >= total) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) % 5, g = idx / (5 * 512);
     const int i = lane & 15, q = lane >> 4;
     const int tap = 2 * s + (q >> 1), c = (q & 1) * 8 + j;
+    const int tap_d = stride == 2 ? kParityTaps[s][q >> 1] : (tap < 9 ? tap : -1);
     float vf = 0.f, vd = 0.f;
-    if (tap < 9) {
-        vf = w[((long)(g * 16 + i) * 16 + c) * 9 + tap];
-        vd = w[((long)(g * 16 + c) * 16 + i) * 9 + tap];
-    }
+    if (tap < 9) vf = w[((long)(g * 16 + i) * 16 + c) * 9 + tap];
+    if (tap_d >= 0) vd = w[((long)(g * 16 + c) * 16 + i) * 9 + tap_d];
     fwd[idx] = (bf16)vf;
     dgr[idx] = (bf16)vd;
 }
@@ -298,6 +302,127 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
     }
 }
 
+// ------------------------------------------------------------------ stride-2 input gradient, LDS row ring
+// dX[h,w] gathers dY[(h+1-kh)/2, (w+1-kw)/2] over the taps whose parities match, so output pixels are processed in
+// fragments of one parity class: 1, 1, 1 and 2 MFMA k-steps per 16 pixels instead of 5 with three quarters of the operand
+// zero.  dY rows y0..y0+R (one row of lookahead) sit in the LDS ring and produce output rows 2*y0 .. 2*(y0+R)-1.
+struct Dgrad2Geom {
+    int N, Ho, Wo, Hi, Wi, C;          // dY is [Ho][Wo], dX is [Hi][Wi]
+    int R;                             // dY rows per step
+    FastDiv fd_px8;                    // 8 * Wo
+};
+
+__global__ __launch_bounds__(256) void conv3x3g_dgrad2_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wp,
+                                                              bf16* __restrict__ dx, Dgrad2Geom gm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int ncb = gm.C >> 6;
+    const int cb = blockIdx.x % ncb, n_first = blockIdx.x / ncb, n_step = gridDim.x / ncb;
+    const int g = cb * 4 + wave;
+    const int Ho = gm.Ho, Wo = gm.Wo, Hi = gm.Hi, Wi = gm.Wi, C = gm.C, R = gm.R, NR = R + 1;
+    const int ROWB = (Wo + 2) * PSB;
+    unsigned char* ring = smem;
+    unsigned char* stage = smem + NR * ROWB;          // [2R*Wi][128 B]
+    bf16x8 wf[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(wp + (((long)g * 5 + s) * 64 + lane) * 8);
+    const int chunk = tid & 7;
+    for (int i = tid; i < NR * 2 * 8; i += 256) {     // halo columns stay zero
+        const int r = i >> 4, side = (i >> 3) & 1, ch = i & 7;
+        *reinterpret_cast<bf16x8*>(ring + r * ROWB + (side ? (Wo + 1) * PSB : 0) + ch * 16) = zero8();
+    }
+    const bf16* img = nullptr;
+    bf16x8 regs[CONV_MAXI];
+    auto fetch = [&](int first, int count) {
+        const int items = count * Wo * 8;
+#pragma unroll
+        for (int k = 0; k < CONV_MAXI; ++k) {
+            const int i = tid + k * 256;
+            regs[k] = zero8();
+            if (i < items) {
+                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
+                const int px = (i - (int)r * Wo * 8) >> 3, ir = first + (int)r;
+                if (ir < Ho) regs[k] = *reinterpret_cast<const bf16x8*>(img + ((long)ir * Wo + px) * C);
+            }
+        }
+    };
+    auto commit = [&](int first, int count) {
+        const int items = count * Wo * 8;
+#pragma unroll
+        for (int k = 0; k < CONV_MAXI; ++k) {
+            const int i = tid + k * 256;
+            if (i < items) {
+                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
+                const int px = (i - (int)r * Wo * 8) >> 3, ir = first + (int)r;
+                *reinterpret_cast<bf16x8*>(ring + (ir % NR) * ROWB + (px + 1) * PSB + chunk * 16) = regs[k];
+            }
+        }
+    };
+    const int ne = (Wi + 1) >> 1, no = Wi >> 1;       // even / odd output columns per row
+    const int fe = (ne + 15) >> 4, fo = (no + 15) >> 4;
+    const int nsteps = (Ho + R - 1) / R;
+    for (int n = n_first; n < gm.N; n += n_step) {
+        img = dy + (long)n * Ho * Wo * C + cb * 64 + chunk * 8;
+        __syncthreads();
+        fetch(0, 1);
+        commit(0, 1);
+        fetch(1, R);
+        for (int st = 0; st < nsteps; ++st) {
+            const int y0 = st * R;
+            commit(y0 + 1, R);
+            __syncthreads();
+            if (st + 1 < nsteps) fetch(y0 + R + 1, R);
+            int out_rows = 2 * R;
+            if (2 * y0 + out_rows > Hi) out_rows = Hi - 2 * y0;
+            for (int rr = 0; rr < out_rows; ++rr) {
+                const int a = rr & 1, y = y0 + (rr >> 1);
+                const int slot_y = (y % NR) * ROWB, slot_y1 = ((y + 1) % NR) * ROWB;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int npx = b ? no : ne, nf = b ? fo : fe;
+                    for (int f = 0; f < nf; ++f) {
+                        int j = f * 16 + p;
+                        const bool valid = j < npx;
+                        if (!valid) j = npx - 1;
+                        const int colb = (j + 1) * PSB + wave * 32 + (q & 1) * 16;    // source column j; + PSB for j + 1
+                        const int hi_half = q >> 1;                                   // second tap of the pair
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        if (a == 0 && b == 0) {
+                            bf16x8 frag = zero8();
+                            if (!hi_half) frag = *reinterpret_cast<const bf16x8*>(ring + slot_y + colb);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], frag, acc, 0, 0, 0);
+                        } else if (a == 0) {          // (1,0): column j + 1, (1,2): column j
+                            const bf16x8 frag = *reinterpret_cast<const bf16x8*>(ring + slot_y + colb + (hi_half ? 0 : PSB));
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], frag, acc, 0, 0, 0);
+                        } else if (b == 0) {          // (0,1): row y + 1, (2,1): row y
+                            const bf16x8 frag = *reinterpret_cast<const bf16x8*>(ring + (hi_half ? slot_y : slot_y1) + colb);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], frag, acc, 0, 0, 0);
+                        } else {                      // (0,0),(0,2): row y + 1; (2,0),(2,2): row y; first of a pair column j + 1
+                            const int cc = colb + (hi_half ? 0 : PSB);
+                            const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(ring + slot_y1 + cc);
+                            const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(ring + slot_y + cc);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[3], f0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[4], f1, acc, 0, 0, 0);
+                        }
+                        if (valid) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[r];
+                            *reinterpret_cast<bf16x4*>(stage + (rr * Wi + 2 * j + b) * 128 + wave * 32 + q * 8) = o;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int P = out_rows * Wi;
+            bf16* out = dx + ((long)(n * Hi + 2 * y0) * Wi) * C + cb * 64 + chunk * 8;
+            for (int px = tid >> 3; px < P; px += 32)
+                *reinterpret_cast<bf16x8*>(out + (long)px * C) = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 constexpr int TH = 4, TW = 8;                 // 32 output pixels per reduction step
 constexpr int MAX_HALO = 9 * 17;              // stride 2: (TH-1)*2+3 by (TW-1)*2+3
@@ -430,10 +555,10 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
 
 #define S(s) ((hipStream_t)(s))
 
-extern "C" int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int G, void* stream) {
-    STES_CHECK(w && wp_fwd && wp_dgrad && G > 0, STES_ERR_ARG, "stes_pack_conv3x3g: null pointer");
+extern "C" int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int G, int stride, void* stream) {
+    STES_CHECK(w && wp_fwd && wp_dgrad && G > 0 && (stride == 1 || stride == 2), STES_ERR_ARG, "stes_pack_conv3x3g: bad argument");
     const int total = G * 5 * 64 * 8;
-    hipLaunchKernelGGL(pack_conv3x3g_kernel, dim3(stes_div_up(total, 256)), dim3(256), 0, S(stream), w, (bf16*)wp_fwd, (bf16*)wp_dgrad, G);
+    hipLaunchKernelGGL(pack_conv3x3g_kernel, dim3(stes_div_up(total, 256)), dim3(256), 0, S(stream), w, (bf16*)wp_fwd, (bf16*)wp_dgrad, G, stride);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -505,6 +630,32 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             }
         }
     }
+    if (mode == 1 && stride == 2) {
+        Dgrad2Geom dg;
+        dg.N = N; dg.Ho = Ho; dg.Wo = Wo; dg.Hi = Hi; dg.Wi = Wi; dg.C = C;
+        auto lds_of = [&](int r) { return (size_t)(r + 1) * (Wo + 2) * PSB + (size_t)2 * r * Wi * 128; };
+        int r = 112 / Wi; if (r < 1) r = 1; if (r > Ho) r = Ho;
+        while (r > 1 && ((long)r * Wo * 8 > CONV_MAXI * 256 || lds_of(r) > 72 * 1024)) --r;
+        STES_CHECK((long)r * Wo * 8 <= CONV_MAXI * 256 && lds_of(r) <= 150 * 1024, STES_ERR_UNSUPPORTED,
+                   "stes_conv3x3g_dgrad: image too wide for the stride-2 LDS tile");
+        dg.R = r; dg.fd_px8 = make_fastdiv(Wo * 8);
+        const size_t lds = lds_of(r);
+        static const bool big = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_dgrad2_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        STES_CHECK(big || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_conv3x3g_dgrad: cannot raise the dynamic LDS limit");
+        static size_t seen_lds[8]; static int seen_val[8], n_seen = 0;
+        int resident = 0;
+        for (int i = 0; i < n_seen; ++i) if (seen_lds[i] == lds) resident = seen_val[i];
+        if (resident == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, conv3x3g_dgrad2_kernel, 256, lds) != hipSuccess || resident < 1) resident = 1;
+            if (n_seen < 8) { seen_lds[n_seen] = lds; seen_val[n_seen] = resident; ++n_seen; }
+        }
+        const int ncb = C / 64;
+        int per = 256 * resident / ncb; if (per < 1) per = 1; if (per > N) per = N;
+        hipLaunchKernelGGL(conv3x3g_dgrad2_kernel, dim3(per * ncb), dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst, dg);
+        STES_LAUNCH_CHECK();
+        return STES_OK;
+    }
     ConvGeom gm;
     gm.N = N; gm.stride = stride; gm.C = C; gm.G = C / 16;
     if (mode == 0) { gm.Hs = Hi; gm.Ws = Wi; gm.Hd = Ho; gm.Wd = Wo; }
@@ -521,7 +672,7 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
 #define CONV_LAUNCH(MODE, ST) hipLaunchKernelGGL((conv3x3g_kernel<MODE, ST>), dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)src, \
         (const bf16*)wp, (bf16*)dst, scale, shift, col_sum, col_sumsq, gm, n_tiles)
     if (mode == 0) { if (stride == 1) CONV_LAUNCH(0, 1); else CONV_LAUNCH(0, 2); }
-    else { if (stride == 1) CONV_LAUNCH(1, 1); else CONV_LAUNCH(1, 2); }
+    else CONV_LAUNCH(1, 1);
 #undef CONV_LAUNCH
     STES_LAUNCH_CHECK();
     return STES_OK;

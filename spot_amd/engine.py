@@ -97,7 +97,7 @@ class Block:
         self.w2 = blk.conv2.conv.weight
         G = self.cmid // 16
         self.wp2_f, self.wp2_d = eng.bf16(G * 5 * 512), eng.bf16(G * 5 * 512)
-        eng.packs.append((self.w2, self.wp2_f, self.wp2_d, G))
+        eng.packs.append((self.w2, self.wp2_f, self.wp2_d, G, self.stride))
         self.se = blk.se
         self.rd = blk.se.fc1.out_channels
         if self.rd % 8:
@@ -485,8 +485,8 @@ class Engine:
             lib.call("stes_cast_bf16", p(src), p(dst), rows, cols, ld, dst_rows, tr, pf)
         for w3d, wt, fold in self.gsm_preps:
             lib.call("stes_gsm_prep", p(w3d), p(wt), fold)
-        for w, wf, wd, G in self.packs:
-            lib.call("stes_pack_conv3x3g", p(w), p(wf), p(wd), G)
+        for w, wf, wd, G, stride in self.packs:
+            lib.call("stes_pack_conv3x3g", p(w), p(wf), p(wd), G, stride)
         self.weights_dirty = False
 
     # ------------------------------------------------------------------ planning

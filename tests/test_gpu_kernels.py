@@ -61,7 +61,7 @@ def test_conv3x3g(stride, H, W, C):
     ref.backward(gy.float())
 
     wp_f = torch.empty(C // 16 * 5 * 512, dtype=BF, device="cuda"); wp_d = torch.empty_like(wp_f)
-    lib.call("stes_pack_conv3x3g", lib.ptr(dev(w)), lib.ptr(wp_f), lib.ptr(wp_d), C // 16)
+    lib.call("stes_pack_conv3x3g", lib.ptr(dev(w)), lib.ptr(wp_f), lib.ptr(wp_d), C // 16, stride)
     out = torch.zeros(N * Ho * Wo, C, dtype=BF, device="cuda")
     s1 = torch.zeros(C, device="cuda"); s2 = torch.zeros(C, device="cuda")
     xd = dev(nhwc(x))

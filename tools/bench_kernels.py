@@ -78,7 +78,7 @@ def bench_conv():
         G = Cc // 16
         w = torch.randn(Cc, 16, 3, 3, device="cuda") * 0.1
         wf, wd = torch.empty(G * 5 * 64 * 8, dtype=torch.bfloat16, device="cuda"), torch.empty(G * 5 * 64 * 8, dtype=torch.bfloat16, device="cuda")
-        lib.call("stes_pack_conv3x3g", lib.ptr(w), lib.ptr(wf), lib.ptr(wd), G)
+        lib.call("stes_pack_conv3x3g", lib.ptr(w), lib.ptr(wf), lib.ptr(wd), G, stride)
         sc, sh = torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda")
         s1, s2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
         dw = torch.zeros(Cc, 16, 3, 3, device="cuda")
