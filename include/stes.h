@@ -103,6 +103,15 @@ int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, co
  * stes_gemm (relu_mask, out_scale = 1/HW) + two stes_wgrad calls.
  * stes_sigmoid_bwd: out[i] = bf16(d[i] * g[i] * (1 - g[i])), the gradient at the sigmoid's input.                */
 int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream);
+/* One pass over (c2, dA3 = gradient at the gated activation) per image: S [4][N][C] = sums over H,W of mask, dA3*mask,
+ * mask*c2, dA3*mask*c2 with mask = [scale*c2 + shift > 0]; dgate [N][C] = gradient at the SE gate.  With the SE backward's
+ * dpool, stes_se_bwd_bnsums turns S into the two BatchNorm-backward sums of conv2.bn (what stes_bn_bwd_reduce would give
+ * for dy = (dA3*gate + dpool)*mask; accumulated with atomics, the caller zeroes them), so that reduction pass over the
+ * tensors is skipped.                                                                                                */
+int stes_se_bwd_pool(const uint16_t* c2, const float* scale, const float* shift, const uint16_t* dA3, float* S,
+                     float* dgate, int N, int HW, int C, void* stream);
+int stes_se_bwd_bnsums(const float* S, const float* gate, const float* dpool, float* s_dy, float* s_dyr, int N, int C,
+                       void* stream);
 
 /* BatchNorm backward.  The incoming gradient is formed on the fly:
  *   dY = (D * mul[m/group] + add[m/group]) * [act_scale*act_raw + act_shift > 0]

@@ -155,6 +155,80 @@ __global__ void chan_pool_kernel(const bf16* __restrict__ c, const float* __rest
     }
 }
 
+// ---------------------------------------------------------------- squeeze-excite backward pooling
+// One pass over (c2, dA3) per image gives everything that depends on them through per-image reductions: with
+// mask = [scale*c2 + shift > 0],   S0 = sum mask, S1 = sum dA3*mask, S2 = sum mask*c2, S3 = sum dA3*mask*c2   (over h,w)
+//   dgate[n,c]          = sum relu(bn(c2)) * dA3                     = scale*S3 + shift*S1
+//   conv2.bn backward   : dy = (dA3*gate + dpool) * mask  =>  sum dy = sum_n gate*S1 + dpool*S0,
+//                                                           sum dy*c2 = sum_n gate*S3 + dpool*S2     (se_bwd_bnsums_kernel)
+// so the BatchNorm reduction pass over the two tensors is not needed.
+__global__ void se_bwd_pool_kernel(const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const bf16* __restrict__ dA, float* __restrict__ S, float* __restrict__ dgate, int N, int HW,
+                                   int C, int R) {
+    extern __shared__ float lds[];     // [R][4][C]
+    const int CH = C / 8;
+    const int n = blockIdx.x;
+    const int chunk = threadIdx.x % CH, rg = threadIdx.x / CH;
+    const int c0 = chunk * 8;
+    float s[8], b[8], a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = 0.f; a1[i] = 0.f; a2[i] = 0.f; a3[i] = 0.f; }
+    load8f(scale + c0, s); load8f(shift + c0, b);
+    const bf16* cb = c + (long)n * HW * C + c0;
+    const bf16* db = dA + (long)n * HW * C + c0;
+    for (int r = rg; r < HW; r += R) {
+        float v[8], d[8];
+        load8b(cb + (long)r * C, v);
+        load8b(db + (long)r * C, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = v[i] * s[i] + b[i] > 0.f;
+            const float m = on ? 1.f : 0.f, dm = on ? d[i] : 0.f;
+            a0[i] += m; a1[i] += dm; a2[i] += m * v[i]; a3[i] += dm * v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float* l = lds + (long)rg * 4 * C + c0 + i;
+        l[0] = a0[i]; l[C] = a1[i]; l[2 * C] = a2[i]; l[3 * C] = a3[i];
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += lds[((long)r * 4 + k) * C + ch];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S[((long)k * N + n) * C + ch] = t[k];
+        dgate[(long)n * C + ch] = scale[ch] * t[3] + shift[ch] * t[1];
+    }
+}
+
+// s_dy[c] += sum_n gate*S1 + dpool*S0;  s_dyr[c] += sum_n gate*S3 + dpool*S2   grid (C/64, image slices), 256 threads =
+// 64 channels x 4 image lanes; one contiguous atomic per slice (the caller zeroes s_dy / s_dyr)
+__global__ __launch_bounds__(256) void se_bwd_bnsums_kernel(const float* __restrict__ S, const float* __restrict__ gate,
+                                                            const float* __restrict__ dpool, float* __restrict__ s_dy,
+                                                            float* __restrict__ s_dyr, int N, int C) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (ch < C) {
+        for (int n = blockIdx.y * 4 + part; n < N; n += 4 * gridDim.y) {
+            const long o = (long)n * C + ch;
+            const float g = gate[o], dp = dpool[o];
+            a += g * S[(long)N * C + o] + dp * S[o];
+            b += g * S[3L * N * C + o] + dp * S[2L * N * C + o];
+        }
+    }
+    red[0][part][cl] = a; red[1][part][cl] = b;
+    __syncthreads();
+    if (part == 0 && ch < C) {
+        atomicAdd(s_dy + ch, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        atomicAdd(s_dyr + ch, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
 // ---------------------------------------------------------------- sigmoid backward (squeeze-excite gate)
 __global__ void sigmoid_bwd_kernel(const float* __restrict__ d, const float* __restrict__ g, bf16* __restrict__ out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -374,6 +448,29 @@ extern "C" int stes_chan_pool(const uint16_t* c, const float* scale, const float
     if (R < 1) R = 1;
     hipLaunchKernelGGL(chan_pool_kernel, dim3(N), dim3(CH * R), (size_t)R * C * sizeof(float), S(stream), (const bf16*)c, scale, shift,
                        (const bf16*)mul, out, (bf16*)out_bf16, HW, C, norm, R);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_se_bwd_pool(const uint16_t* c2, const float* scale, const float* shift, const uint16_t* dA3, float* S,
+                                float* dgate, int N, int HW, int C, void* stream) {
+    STES_CHECK(c2 && scale && shift && dA3 && S && dgate && N > 0 && HW > 0, STES_ERR_ARG, "stes_se_bwd_pool: null pointer");
+    STES_CHECK(C % 8 == 0 && C / 8 <= TPB, STES_ERR_ARG, "stes_se_bwd_pool: C must be a multiple of 8, at most 2048");
+    const int CH = C / 8;
+    int R = TPB / CH;
+    if (R > HW) R = HW;
+    if (R < 1) R = 1;
+    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(N), dim3(CH * R), (size_t)R * 4 * C * sizeof(float), S(stream), (const bf16*)c2, scale, shift,
+                       (const bf16*)dA3, S, dgate, N, HW, C, R);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_se_bwd_bnsums(const float* S, const float* gate, const float* dpool, float* s_dy, float* s_dyr, int N, int C,
+                                  void* stream) {
+    STES_CHECK(S && gate && dpool && s_dy && s_dyr && N > 0 && C > 0, STES_ERR_ARG, "stes_se_bwd_bnsums: null pointer");
+    int slices = N / 32; if (slices < 1) slices = 1; if (slices > 64) slices = 64;
+    hipLaunchKernelGGL(se_bwd_bnsums_kernel, dim3(stes_div_up(C, 64), slices), dim3(256), 0, S(stream), S, gate, dpool, s_dy, s_dyr, N, C);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

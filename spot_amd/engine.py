@@ -210,7 +210,8 @@ class Block:
         lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
         # --- squeeze-excite backward
         dgate = sc("se.dgate", self.N * cmid, F32)
-        lib.call("stes_chan_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(dgate), None, self.N, HWo, cmid, 1.0)
+        S4 = sc("se.S4", 4 * self.N * cmid, F32)
+        lib.call("stes_se_bwd_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(S4), p(dgate), self.N, HWo, cmid)
         dpre2, dpre1, dpool = sc("se.dpre2", self.N * cmid), sc("se.dpre1", self.N * self.rd), sc("se.dpool", self.N * cmid, F32)
         se, rd = self.se, self.rd
         lib.call("stes_sigmoid_bwd", p(dgate), p(self.segate), p(dpre2), self.N * cmid)
@@ -220,7 +221,7 @@ class Block:
         lib.wgrad(dpre1, self.pooled, g(se.fc1.weight), self.N, rd, cmid, dbias=g(se.fc1.bias))
         # --- conv2.bn backward: dY2 = (dA3*gate + dpool) * [bn2(c2) > 0]
         kw2 = dict(mul=self.segate, add=dpool, group=HWo, act=(self.c2, bn2.scale, bn2.shift))
-        lib.bn_bwd_reduce(dA3, self.c2, Mo, cmid, [bn2.s_dy, bn2.s_dyr], **kw2)
+        lib.call("stes_se_bwd_bnsums", p(S4), p(self.segate), p(dpool), p(bn2.s_dy), p(bn2.s_dyr), self.N, cmid)
         bn2.bwd_finalize(Mo)
         dc2 = sc("dc2", Mo * cmid)
         lib.bn_bwd_apply(dA3, self.c2, Mo, cmid, bn2.coef, dc2, **kw2)

@@ -70,6 +70,8 @@ _SIGS = {
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
+    "stes_se_bwd_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_se_bwd_bnsums": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "stes_bn_bwd_reduce": [_P, _P],
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
     "stes_bn_bwd_apply": [_P, _P],

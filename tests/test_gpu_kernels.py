@@ -186,6 +186,30 @@ def test_se(Cc, R, HW):
     close(pf, (a * mul.float().view(N, HW, Cc)).sum(1), 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("Cc,HW", [(64, 49), (320, 30), (768, 12)])
+def test_se_backward_pool_gives_gate_gradient_and_bn_sums(Cc, HW):
+    """stes_se_bwd_pool + stes_se_bwd_bnsums against the direct formulas: dgate = sum_hw relu(bn(c2)) * dA3 and the two
+    BatchNorm-backward sums of dy = (dA3*gate + dpool) * [bn(c2) > 0]."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(Cc + HW)
+    N = 6
+    c2, dA = bfr(N * HW, Cc, g=g), bfr(N * HW, Cc, g=g)
+    scale, shift = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    gate, dpool = torch.rand(N, Cc, generator=g), torch.randn(N, Cc, generator=g) * 0.1
+    x = c2.float().view(N, HW, Cc); d = dA.float().view(N, HW, Cc)
+    pre = x * scale + shift
+    dgate_ref = (torch.relu(pre) * d).sum(1)
+    dy = (d * gate[:, None] + dpool[:, None]) * (pre > 0)
+    S = torch.empty(4, N, Cc, device="cuda"); dg = torch.empty(N, Cc, device="cuda")
+    lib.call("stes_se_bwd_pool", lib.ptr(dev(c2)), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dev(dA)), lib.ptr(S), lib.ptr(dg), N, HW, Cc)
+    s_dy = torch.zeros(Cc, device="cuda"); s_dyr = torch.zeros(Cc, device="cuda")
+    lib.call("stes_se_bwd_bnsums", lib.ptr(S), lib.ptr(dev(gate)), lib.ptr(dev(dpool)), lib.ptr(s_dy), lib.ptr(s_dyr), N, Cc)
+    torch.cuda.synchronize()
+    close(dg, dgate_ref, 1e-3, 1e-3)
+    close(s_dy, dy.sum((0, 1)), 1e-3, 1e-3)
+    close(s_dyr, (dy * x).sum((0, 1)), 1e-3, 2e-3)
+
+
 def test_bn_backward_chain():
     """dY = (D*mul + add) * relu-mask, then BatchNorm (training) backward: reduce -> finalize -> apply."""
     from spot_amd import lib
