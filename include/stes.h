@@ -152,8 +152,12 @@ int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int
 int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
                       const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
                       int stride, int C, void* stream);
-int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, int N, int Hi, int Wi, int Ho,
-                        int Wo, int stride, int C, void* stream);
+/* Input gradient.  With mask_raw (the raw conv1 output [N*Hi*Wi][C] whose BatchNorm+ReLU fed this convolution) the result is
+ * multiplied by [mask_scale*raw + mask_shift > 0] and the BatchNorm-backward sums s_dy[c] += sum din, s_dyr[c] += sum din*raw
+ * are accumulated (atomics; caller zeroes), replacing a stes_bn_bwd_reduce pass.                                         */
+int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, const uint16_t* mask_raw,
+                        const float* mask_scale, const float* mask_shift, float* s_dy, float* s_dyr, int N, int Hi, int Wi,
+                        int Ho, int Wo, int stride, int C, void* stream);
 /* dw [C][16][3][3] fp32 += (atomics; caller zeroes) */
 int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, const float* in_scale, const float* in_shift, float* dw,
                         int N, int Hi, int Wi, int Ho, int Wo, int stride, int C, void* stream);

@@ -152,7 +152,10 @@ template <int STRIDE, bool FLIP>
 __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
                                                             bf16* __restrict__ dst, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* col_sum, float* col_sumsq,
-                                                            RowsGeom gm) {
+                                                            const bf16* __restrict__ mask_raw, RowsGeom gm) {
+    // FLIP with mask_raw: the result is the gradient at a ReLU(BatchNorm(raw)) output; it is masked with
+    // [scale*raw + shift > 0] on its way out and the BatchNorm-backward sums (sum dy -> col_sum, sum dy*raw -> col_sumsq)
+    // are accumulated here, which saves the separate reduction pass over both tensors.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, q = lane >> 4;
@@ -169,11 +172,12 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
     bf16x8 wf[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(wp + (((long)g * 5 + s) * 64 + lane) * 8);
-    const bool affine = scale != nullptr;
+    const bool masked = FLIP && mask_raw != nullptr;
+    const bool affine = !FLIP && scale != nullptr;
     const bool stats = col_sum != nullptr;
     const int chunk = tid & 7;                        // this thread's 8 channels in the staging / store phases
     float sc[8], sh[8];
-    if (affine) { load8f(scale + cb * 64 + chunk * 8, sc); load8f(shift + cb * 64 + chunk * 8, sh); }
+    if (affine || masked) { load8f(scale + cb * 64 + chunk * 8, sc); load8f(shift + cb * 64 + chunk * 8, sh); }
     float ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
@@ -282,9 +286,22 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
         }
         __syncthreads();
         // staged pixels -> global, 128 contiguous bytes per pixel (fully contiguous when C == 64)
-        bf16* out = dst + ((long)(n * Hd + row0) * Wd) * C + cb * 64 + chunk * 8;
+        const long obase = ((long)(n * Hd + row0) * Wd) * C + cb * 64 + chunk * 8;
+        bf16* out = dst + obase;
         for (int px = tid >> 3; px < P; px += 32) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+            if (masked) {
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(mask_raw + obase + (long)px * C);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = (float)raw[e];
+                    if (!(r * sc[e] + sh[e] > 0.f)) v[e] = (bf16)0.f;
+                    const float fv = (float)v[e];
+                    ssum[e] += fv; ssq[e] += fv * r;
+                }
+                *reinterpret_cast<bf16x8*>(out + (long)px * C) = v;
+                continue;
+            }
             *reinterpret_cast<bf16x8*>(out + (long)px * C) = v;
             if (stats) {
 #pragma unroll
@@ -313,7 +330,9 @@ struct Dgrad2Geom {
 };
 
 __global__ __launch_bounds__(256) void conv3x3g_dgrad2_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wp,
-                                                              bf16* __restrict__ dx, Dgrad2Geom gm) {
+                                                              bf16* __restrict__ dx, const bf16* __restrict__ mask_raw,
+                                                              const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                              float* s_dy, float* s_dyr, Dgrad2Geom gm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, q = lane >> 4;
@@ -324,6 +343,13 @@ __global__ __launch_bounds__(256) void conv3x3g_dgrad2_kernel(const bf16* __rest
     const int ROWB = (Wo + 2) * PSB;
     unsigned char* ring = smem;
     unsigned char* stage = smem + NR * ROWB;          // [2R*Wi][128 B]
+    float* red = reinterpret_cast<float*>(stage + 2 * R * Wi * 128);   // [2][64]
+    const bool masked = mask_raw != nullptr;          // see conv3x3g_rows_kernel
+    float sc[8], sh[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; }
+    if (masked) { load8f(mscale + cb * 64 + (tid & 7) * 8, sc); load8f(mshift + cb * 64 + (tid & 7) * 8, sh); }
+    if (tid < 128) red[tid] = 0.f;
     bf16x8 wf[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(wp + (((long)g * 5 + s) * 64 + lane) * 8);
@@ -416,10 +442,29 @@ __global__ __launch_bounds__(256) void conv3x3g_dgrad2_kernel(const bf16* __rest
             }
             __syncthreads();
             const int P = out_rows * Wi;
-            bf16* out = dx + ((long)(n * Hi + 2 * y0) * Wi) * C + cb * 64 + chunk * 8;
-            for (int px = tid >> 3; px < P; px += 32)
-                *reinterpret_cast<bf16x8*>(out + (long)px * C) = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+            const long obase = ((long)(n * Hi + 2 * y0) * Wi) * C + cb * 64 + chunk * 8;
+            bf16* out = dx + obase;
+            for (int px = tid >> 3; px < P; px += 32) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
+                if (masked) {
+                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(mask_raw + obase + (long)px * C);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float r = (float)raw[e];
+                        if (!(r * sc[e] + sh[e] > 0.f)) v[e] = (bf16)0.f;
+                        const float fv = (float)v[e];
+                        ssum[e] += fv; ssq[e] += fv * r;
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(out + (long)px * C) = v;
+            }
         }
+    }
+    if (masked) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); }
+        __syncthreads();
+        if (tid < 128) atomicAdd((tid < 64 ? s_dy : s_dyr) + cb * 64 + (tid & 63), red[tid]);
     }
 }
 
@@ -564,7 +609,8 @@ extern "C" int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp
 }
 
 static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16_t* dst, const float* scale, const float* shift,
-                       float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo, int stride, int C, void* stream) {
+                       float* col_sum, float* col_sumsq, const uint16_t* mask_raw, int N, int Hi, int Wi, int Ho, int Wo, int stride,
+                       int C, void* stream) {
     STES_CHECK(src && wp && dst, STES_ERR_ARG, "stes_conv3x3g: null pointer");
     STES_CHECK(C % 64 == 0, STES_ERR_ARG, "stes_conv3x3g: channels must be a multiple of 64 (groups of 16, 4 per workgroup)");
     STES_CHECK(stride == 1 || stride == 2, STES_ERR_ARG, "stes_conv3x3g: stride must be 1 or 2");
@@ -620,7 +666,7 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             const dim3 grid(per * ncb);
             if (big_lds || lds <= 64 * 1024) {
 #define ROWS_LAUNCH(ST, FL) hipLaunchKernelGGL((conv3x3g_rows_kernel<ST, FL>), grid, dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, \
-        (bf16*)dst, scale, shift, col_sum, col_sumsq, rg)
+        (bf16*)dst, scale, shift, col_sum, col_sumsq, (const bf16*)mask_raw, rg)
                 if (mode == 1) ROWS_LAUNCH(1, true);
                 else if (stride == 1) ROWS_LAUNCH(1, false);
                 else ROWS_LAUNCH(2, false);
@@ -633,7 +679,7 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     if (mode == 1 && stride == 2) {
         Dgrad2Geom dg;
         dg.N = N; dg.Ho = Ho; dg.Wo = Wo; dg.Hi = Hi; dg.Wi = Wi; dg.C = C;
-        auto lds_of = [&](int r) { return (size_t)(r + 1) * (Wo + 2) * PSB + (size_t)2 * r * Wi * 128; };
+        auto lds_of = [&](int r) { return (size_t)(r + 1) * (Wo + 2) * PSB + (size_t)2 * r * Wi * 128 + 128 * sizeof(float); };
         int r = 112 / Wi; if (r < 1) r = 1; if (r > Ho) r = Ho;
         while (r > 1 && ((long)r * Wo * 8 > CONV_MAXI * 256 || lds_of(r) > 72 * 1024)) --r;
         STES_CHECK((long)r * Wo * 8 <= CONV_MAXI * 256 && lds_of(r) <= 150 * 1024, STES_ERR_UNSUPPORTED,
@@ -652,10 +698,12 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
         }
         const int ncb = C / 64;
         int per = 256 * resident / ncb; if (per < 1) per = 1; if (per > N) per = N;
-        hipLaunchKernelGGL(conv3x3g_dgrad2_kernel, dim3(per * ncb), dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst, dg);
+        hipLaunchKernelGGL(conv3x3g_dgrad2_kernel, dim3(per * ncb), dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst,
+                           (const bf16*)mask_raw, scale, shift, col_sum, col_sumsq, dg);
         STES_LAUNCH_CHECK();
         return STES_OK;
     }
+    STES_CHECK(!mask_raw, STES_ERR_UNSUPPORTED, "stes_conv3x3g_dgrad: image too wide for the fused mask + BatchNorm sums");
     ConvGeom gm;
     gm.N = N; gm.stride = stride; gm.C = C; gm.G = C / 16;
     if (mode == 0) { gm.Hs = Hi; gm.Ws = Wi; gm.Hd = Ho; gm.Wd = Wo; }
@@ -681,12 +729,15 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
 extern "C" int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
                                  const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
                                  int stride, int C, void* stream) {
-    return conv_launch(0, in, wp_fwd, out, in_scale, in_shift, col_sum, col_sumsq, N, Hi, Wi, Ho, Wo, stride, C, stream);
+    return conv_launch(0, in, wp_fwd, out, in_scale, in_shift, col_sum, col_sumsq, nullptr, N, Hi, Wi, Ho, Wo, stride, C, stream);
 }
 
-extern "C" int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, int N, int Hi, int Wi, int Ho,
-                                   int Wo, int stride, int C, void* stream) {
-    return conv_launch(1, dout, wp_dgrad, din, nullptr, nullptr, nullptr, nullptr, N, Hi, Wi, Ho, Wo, stride, C, stream);
+extern "C" int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, const uint16_t* mask_raw,
+                                   const float* mask_scale, const float* mask_shift, float* s_dy, float* s_dyr, int N, int Hi,
+                                   int Wi, int Ho, int Wo, int stride, int C, void* stream) {
+    STES_CHECK(!mask_raw || (mask_scale && mask_shift && s_dy && s_dyr), STES_ERR_ARG, "stes_conv3x3g_dgrad: the mask needs its affine and both sums");
+    return conv_launch(1, dout, wp_dgrad, din, mask_raw ? mask_scale : nullptr, mask_raw ? mask_shift : nullptr, mask_raw ? s_dy : nullptr,
+                       mask_raw ? s_dyr : nullptr, mask_raw, N, Hi, Wi, Ho, Wo, stride, C, stream);
 }
 
 extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, const float* in_scale, const float* in_shift, float* dw,

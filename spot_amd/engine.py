@@ -229,13 +229,11 @@ class Block:
         geo = (self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
         lib.call("stes_conv3x3g_wgrad", p(dc2), p(self.c1), p(bn1.scale), p(bn1.shift), p(g(self.w2)), *geo)
         dA2 = sc("dA2", Mi * cmid)
-        lib.call("stes_conv3x3g_dgrad", p(dc2), p(self.wp2_d), p(dA2), *geo)
-        # --- conv1.bn backward: dY1 = dA2 * [bn1(c1) > 0]
-        kw1 = dict(act=(self.c1, bn1.scale, bn1.shift))
-        lib.bn_bwd_reduce(dA2, self.c1, Mi, cmid, [bn1.s_dy, bn1.s_dyr], **kw1)
+        # conv1.bn backward, first half: the input-gradient kernel masks with [bn1(c1) > 0] and accumulates the sums
+        lib.call("stes_conv3x3g_dgrad", p(dc2), p(self.wp2_d), p(dA2), p(self.c1), p(bn1.scale), p(bn1.shift), p(bn1.s_dy), p(bn1.s_dyr), *geo)
         bn1.bwd_finalize(Mi)
         dc1 = sc("dc1", Mi * cmid)
-        lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1, **kw1)
+        lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1)
         # --- conv1 (1x1)
         q0, k0 = (self.G, self.fold) if self.kind == "gsm" else (None, 0)
         lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold)

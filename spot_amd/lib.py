@@ -79,7 +79,7 @@ _SIGS = {
     "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_pack_conv3x3g": [_P, _P, _P, _I32, _I32, _P],
     "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
-    "stes_conv3x3g_dgrad": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_conv3x3g_dgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stes_gsm_prep": [_P, _P, _I32, _P],

@@ -74,9 +74,20 @@ def test_conv3x3g(stride, H, W, C):
     # dgrad
     din = torch.zeros(N * H * W, C, dtype=BF, device="cuda")
     gyd = dev(nhwc(gy))
-    lib.call("stes_conv3x3g_dgrad", lib.ptr(gyd), lib.ptr(wp_d), lib.ptr(din), N, H, W, Ho, Wo, stride, C)
+    lib.call("stes_conv3x3g_dgrad", lib.ptr(gyd), lib.ptr(wp_d), lib.ptr(din), None, None, None, None, None, N, H, W, Ho, Wo, stride, C)
     torch.cuda.synchronize()
     close(nchw(din.cpu(), N, H, W), xin.grad, 1e-2, 2e-2)
+    # dgrad fused with the ReLU mask of the producing BatchNorm and its backward sums
+    dinm = torch.zeros(N * H * W, C, dtype=BF, device="cuda")
+    sdy = torch.zeros(C, device="cuda"); sdyr = torch.zeros(C, device="cuda")
+    lib.call("stes_conv3x3g_dgrad", lib.ptr(gyd), lib.ptr(wp_d), lib.ptr(dinm), lib.ptr(xd), lib.ptr(dev(scale)), lib.ptr(dev(shift)),
+             lib.ptr(sdy), lib.ptr(sdyr), N, H, W, Ho, Wo, stride, C)
+    torch.cuda.synchronize()
+    xr = nhwc(x).float()
+    on = (xr * scale + shift) > 0
+    assert torch.equal(dinm.cpu(), torch.where(on, din.cpu(), torch.zeros((), dtype=BF)))
+    close(sdy, dinm.float().cpu().sum(0), 1e-3, 1e-2)
+    close(sdyr, (dinm.float().cpu() * xr).sum(0), 1e-3, 2e-2)
     # wgrad
     dw = torch.zeros(C, 16, 3, 3, device="cuda")
     lib.call("stes_conv3x3g_wgrad", lib.ptr(gyd), lib.ptr(xd), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dw),
