@@ -161,22 +161,52 @@ def tsm_shift(x, n_segment, fold_div=8):
     return out.reshape(nt, c, h, w)
 
 
+class _ReluLateMask(torch.autograd.Function):
+    """ReLU whose backward mask can be replaced after the forward.  The reference's in-place shift (InplaceShift,
+    model/shift.py:55-66) overwrites the storage of the previous layer's ReLU output through `.data`, and ReLU's backward
+    multiplies by (saved output > 0): the mask therefore comes from the SHIFTED values."""
+
+    @staticmethod
+    def forward(ctx, y, holder):
+        out = y.clamp_min(0)
+        holder["mask"] = out > 0
+        ctx.holder = holder
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.holder["mask"], None
+
+
+def relu_late(y):
+    """relu(y) carrying the handle a following TemporalShift uses to swap the backward mask."""
+    holder = {}
+    out = q(_ReluLateMask.apply(y, holder))
+    out._late_mask = holder
+    return out
+
+
 class TemporalShift(nn.Module):
-    """reference model/shift.py:21-35 with inplace=True semantics: the reference
-    shifts the caller's storage (InplaceShift, :55-66), so the block's residual
-    shortcut sees the SHIFTED tensor.  `forward` returns (conv(shifted), shifted)
-    through the `last_shifted` attribute so that Bottleneck can mirror that."""
+    """reference model/shift.py:21-35 with inplace=True semantics.  The reference shifts the caller's storage
+    (InplaceShift, :55-66) and returns it; autograd sees three consequences, all reproduced here:
+      * the wrapped conv reads the shifted tensor and its gradient passes through the adjoint shift (:68-78);
+      * the block's residual shortcut still holds the ORIGINAL tensor object: it reads the shifted values, but its
+        gradient reaches the previous layer without the adjoint shift (`last_shortcut`);
+      * the previous layer's ReLU backward masks with the shifted values (`_ReluLateMask`)."""
 
     def __init__(self, net, n_segment, n_div=8):
         super().__init__()
         self.net = net
         self.n_segment = n_segment
         self.fold_div = n_div
-        self.last_shifted = None
+        self.last_shortcut = None
 
     def forward(self, x):
         s = tsm_shift(x, self.n_segment, self.fold_div)
-        self.last_shifted = s
+        holder = getattr(x, "_late_mask", None)
+        if holder is not None and torch.is_grad_enabled():
+            holder["mask"] = s.detach() > 0
+        self.last_shortcut = x + (s - x).detach()          # value of s, gradient of x
         return self.net(s)
 
 
@@ -193,7 +223,7 @@ class ConvBnAct(nn.Module):
     def forward(self, x):
         x = q(self.conv(x))
         x = self.bn(x)
-        return F.relu(x) if self.apply_act else x
+        return relu_late(x) if self.apply_act else x
 
 
 class SEModule(nn.Module):
@@ -225,12 +255,12 @@ class Bottleneck(nn.Module):
         shortcut = x
         y = self.conv1(x)
         if isinstance(self.conv1, TemporalShift):
-            shortcut = self.conv1.last_shifted          # in-place shift aliasing
+            shortcut = self.conv1.last_shortcut         # in-place shift aliasing
         y = self.conv2(y)
         y = self.se(y)
         y = self.conv3(y)
         y = y + self.downsample(shortcut)
-        return q(F.relu(y))
+        return relu_late(y)
 
 
 class _Head(nn.Module):

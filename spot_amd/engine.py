@@ -383,12 +383,16 @@ class Engine:
     def _flatten(self):
         impl = self.impl
         named = [(n, p) for n, p in impl.named_parameters() if p.requires_grad]
-        # GRU: put the two directions of each tensor kind next to each other
+        # GRU: put the two directions of each tensor kind next to each other; minGRU: the gate and the candidate
+        # projection of a layer (so that each pair is one [2H, I] matrix in the flat buffer)
         def key(item):
             n = item[0]
             if "._gru." in n or n.startswith("_pred_fine._gru."):
                 base = n.replace("_reverse", "")
                 return (base, 1 if n.endswith("_reverse") else 0)
+            if ".rnn_layers." in n and (".linear_z." in n or ".linear_h_tilde." in n):
+                base = n.replace(".linear_h_tilde.", ".linear_z.")
+                return (base, 1 if ".linear_h_tilde." in n else 0)
             return None
         gru = sorted([it for it in named if key(it) is not None], key=key)
         rest = [it for it in named if key(it) is None]
@@ -460,15 +464,13 @@ class Engine:
             self.fc = Linear(self, pf._fc_out._fc_out.weight, pf._fc_out._fc_out.bias)
             self.drop_p = float(pf._dropout.p)
         elif self.head_kind == "mingru":
-            self.min_layers = []
-            for layer in pf.rnn_layers:
-                # gate and candidate projections fused into one [2H, I] GEMM: needs adjacent weights -> private stacked copy
-                self.min_layers.append(layer)
             self.fc = Linear(self, pf.fc.weight, pf.fc.bias)
+            # gate and candidate projections of a layer as one [2H, I] matrix (adjacent in the flat buffer, see _flatten)
             self.min_lin = []
             for layer in pf.rnn_layers:
-                self.min_lin.append((Linear(self, layer.linear_z.weight, layer.linear_z.bias),
-                                     Linear(self, layer.linear_h_tilde.weight, layer.linear_h_tilde.bias)))
+                w = self.pair_view([layer.linear_z.weight, layer.linear_h_tilde.weight])
+                b = self.pair_view([layer.linear_z.bias, layer.linear_h_tilde.bias])
+                self.min_lin.append(Linear(self, w, b))
         else:
             self.fc = Linear(self, pf._fc_out.weight, pf._fc_out.bias)
         self.loc = None
@@ -602,10 +604,9 @@ class Engine:
             lib.gemm(self.fc_in, self.fc.w_bf, self.logits, N, self.fc.N, in_dim, bias=self.fc.b)
         elif self.head_kind == "mingru":
             xin, in_dim = feat, Fd
-            for i, (lz, lh) in enumerate(self.min_lin):
-                Hh = lz.N
-                lib.gemm(xin, lz.w_bf, self.min_pre[i], N, Hh, in_dim, bias=lz.b, ldc=2 * Hh)
-                lib.gemm(xin, lh.w_bf, self.min_pre[i][Hh:], N, Hh, in_dim, bias=lh.b, ldc=2 * Hh)
+            for i, lin in enumerate(self.min_lin):
+                Hh = lin.N // 2
+                lib.gemm(xin, lin.w_bf, self.min_pre[i], N, 2 * Hh, in_dim, bias=lin.b)
                 lib.call("stes_mingru_scan_fwd", p(self.min_pre[i]), p(self.impl._pred_fine.h0[i]), p(self.min_h[i]), B, T, Hh)
                 xin, in_dim = self.min_h[i], Hh
             self.fc_in = xin
@@ -628,10 +629,6 @@ class Engine:
         p, g, sc = lib.ptr, self.grad, self.scratch
         if self.Th != T:
             raise NotImplementedError("backward needs clips of exactly clip_len frames")
-        if self.head_kind == "mingru":
-            raise NotImplementedError("training through the minGRU head is not built yet (inference only)")
-        if any(b.kind == "tsm" for b in self.blocks):
-            raise NotImplementedError("training through the plain temporal shift is not built yet (inference only)")
         dfa = sc("dfeat.a", N * Fd, F32)
         dfb = None
         fc = self.fc
@@ -663,6 +660,23 @@ class Engine:
                     dy = sc(f"gru.dy{li}", N * L.I, F32)
                     lib.gemm(dgi, L.lin.wT_bf, dy, N, L.I, 6 * Hh, ldw=L.lin.Np)
                 mask = None
+        elif self.head_kind == "mingru":
+            Hh = self.min_lin[-1].N // 2
+            lib.wgrad(dlogits_bf, self.fc_in, g(fc.w), N, fc.N, Hh, ldp=ncp, dbias=g(fc.b))
+            dh = sc("min.dh", N * Hh, F32)
+            lib.gemm(dlogits_bf, fc.wT_bf, dh, N, Hh, ncp, ldw=fc.Np)
+            for i in range(len(self.min_lin) - 1, -1, -1):
+                lin = self.min_lin[i]
+                Hh = lin.N // 2
+                dpre = sc("min.dpre", N * 2 * Hh)
+                lib.call("stes_mingru_scan_bwd", p(self.min_pre[i]), p(self.impl._pred_fine.h0[i]), p(self.min_h[i]), p(dh), Hh, p(dpre), B, T, Hh)
+                xin = self.feat if i == 0 else self.min_h[i - 1]
+                lib.wgrad(dpre, xin, g(lin.w), N, 2 * Hh, lin.K, dbias=g(lin.b))
+                if i == 0:
+                    lib.gemm(dpre, lin.wT_bf, dfa, N, Fd, 2 * Hh, ldw=lin.Np)
+                else:
+                    dh = sc(f"min.dh{i}", N * lin.K, F32)
+                    lib.gemm(dpre, lin.wT_bf, dh, N, lin.K, 2 * Hh, ldw=lin.Np)
         else:
             lib.wgrad(dlogits_bf, self.feat, g(fc.w), N, fc.N, Fd, ldp=ncp, dbias=g(fc.b))
             lib.gemm(dlogits_bf, fc.wT_bf, dfa, N, Fd, ncp, ldw=fc.Np)

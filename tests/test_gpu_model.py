@@ -58,20 +58,22 @@ def test_eval_forward_vs_reference_golden(golden):
     np.testing.assert_allclose(loc, oloc, atol=2e-2)
 
 
-def test_train_forward_backward_vs_reference_and_oracle(golden):
+@pytest.mark.parametrize("arch,tarch,tag", [("rny008_gsm", "gru", "full_rny008_gsm_gru"), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru")])
+def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag):
+    """Training-mode outputs, loss and every parameter gradient against the reference's own fp32 run (golden) -- for the
+    plain temporal shift this includes the autograd consequences of the reference's in-place shift (model/shift.py:55-78):
+    unshifted shortcut gradient, ReLU mask taken from the shifted tensor."""
     from oracle import stes_oracle as O
-    z = golden("full_rny008_gsm_gru")
-    om, m = build()
+    z = golden(tag)
+    om, m = build(arch, tarch)
     x, label, xy = torch.from_numpy(z["x"]), torch.from_numpy(z["label"]), torch.from_numpy(z["xy"])
     impl = m._model
     impl.train()
-    impl._pred_fine._dropout.p = 0.0
-    impl.engine.drop_p = 0.0
+    if tarch == "gru":
+        impl._pred_fine._dropout.p = 0.0
+        impl.engine.drop_p = 0.0
     d = impl(x.cuda())
-    for k in ("cnn_feat", "im_feat", "loc_feat"):
-        r = rel(d[k].detach().cpu(), z["train." + k])
-        print(k, "train rel L2 vs reference fp32:", r)
-        assert r < 3e-2, (k, r)
+    fwd_dev = {k: rel(d[k].detach().cpu(), z["train." + k]) for k in ("cnn_feat", "im_feat", "loc_feat")}
     # reference-style loss with torch ops on top of the engine outputs, backward through the autograd bridge
     loss, lc, ll = None, None, None
     import torch.nn.functional as F
@@ -87,25 +89,33 @@ def test_train_forward_backward_vs_reference_and_oracle(golden):
     # oracle with the kernels' bf16 storage rounding
     O.set_storage_rounding(True)
     try:
-        om.train(); om._pred_fine._dropout.p = 0.0
+        om.train()
+        if tarch == "gru":
+            om._pred_fine._dropout.p = 0.0
         od = om(x)
         oloss, _, _ = O.stes_loss(od["im_feat"], od["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
         oloss.backward()
     finally:
         O.set_storage_rounding(False)
     for k in ("cnn_feat", "im_feat", "loc_feat"):
+        # yardstick: what bf16 storage alone does to this output in the CPU oracle (training-mode BatchNorm over 8 frames
+        # amplifies rounding noise; the location head's small outputs carry the most)
+        yard = rel(od[k].detach(), z["train." + k])
         r = rel(d[k].detach().cpu(), od[k].detach())
-        print(k, "train rel L2 vs bf16-rounded oracle:", r)
-        assert r < 4e-2, (k, r)
+        print(k, "train rel L2 vs reference fp32: %.4f (bf16 oracle: %.4f); vs bf16-rounded oracle: %.4f" % (fwd_dev[k], yard, r))
+        assert fwd_dev[k] < max(3e-2, 2.0 * yard), (k, fwd_dev[k], yard)
+        assert r < max(4e-2, 2.5 * yard), (k, r)
     # Gradients.  bf16 storage noise flips ReLU masks of near-zero pre-activations, and every flipped element changes
     # the masked gradient by its full size, so through ~45 ReLU layers the fp32 gradient cannot be matched tightly on a
     # batch of 8 frames: the CPU oracle run with bf16 storage rounding deviates from its own fp32 run by 20-40 % in
     # the backbone (2 % in the heads).  That self-deviation is the yardstick: per tensor, the HIP gradient must be as
     # close to the reference's fp32 gradient as the bf16-rounded oracle is (ratio of the two deviations: median < 1.3,
     # 95th percentile < 2, max < 3.5 over all tensors), with cosine > 0.75.
-    om32 = O.Impl(7, "rny008_gsm", "gru", clip_len=4, predict_location=True)
+    om32 = O.Impl(7, arch, tarch, clip_len=4, predict_location=True)
     O.randomize_(om32, seed=3)
-    om32.train(); om32._pred_fine._dropout.p = 0.0
+    om32.train()
+    if tarch == "gru":
+        om32._pred_fine._dropout.p = 0.0
     o32 = om32(x)
     l32, _, _ = O.stes_loss(o32["im_feat"], o32["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
     l32.backward()

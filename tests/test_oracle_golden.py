@@ -162,10 +162,9 @@ def test_full_model(golden, arch, tarch, tag):
         d = m(x)
     for k in ("im_feat", "loc_feat", "cnn_feat"):
         np.testing.assert_allclose(d[k].numpy(), z["eval." + k], rtol=1e-4, atol=1e-5)
-    if tarch != "gru":
-        return
     m.train()
-    m._pred_fine._dropout.p = 0.0
+    if tarch == "gru":
+        m._pred_fine._dropout.p = 0.0
     d = m(x)
     for k in ("im_feat", "loc_feat", "cnn_feat"):
         np.testing.assert_allclose(d[k].detach().numpy(), z["train." + k], rtol=1e-4, atol=1e-5)
@@ -178,7 +177,14 @@ def test_full_model(golden, arch, tarch, tag):
             continue
         assert abs(p.grad.double().norm().item() - norms[n]) <= 2e-3 * norms[n] + 1e-7, n
         if "g." + n in z.files:
-            np.testing.assert_allclose(p.grad.numpy(), z["g." + n], rtol=2e-3, atol=1e-5 * (1 + norms[n]))
+            if tarch == "gru":
+                np.testing.assert_allclose(p.grad.numpy(), z["g." + n], rtol=2e-3, atol=1e-5 * (1 + norms[n]))
+            else:
+                # the in-place shift variant was generated through strided views: its fp32 pre-activations differ from this
+                # run's in the last bits, which flips the odd ReLU at zero (one element changes a channel's gradient by
+                # percents); the tensors agree to a few 1e-3 in relative L2, the reference's autograd quirks would show as 1e-1
+                g = z["g." + n]
+                assert np.linalg.norm(p.grad.numpy() - g) <= 5e-3 * np.linalg.norm(g), n
     for n, b in m.named_buffers():
         if "buf." + n in z.files:
             np.testing.assert_allclose(b.numpy(), z["buf." + n], rtol=1e-5, atol=1e-6)

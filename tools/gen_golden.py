@@ -287,9 +287,11 @@ class _RefComposite(nn.Module):
         return {"im_feat": self._pred_fine(im), "loc_feat": self._pred_loc(im), "cnn_feat": im}
 
 
-def gen_full():
+def gen_full(only=None):
     import torch.nn.functional as F
     for arch, tarch, tag in (("rny008_gsm", "gru", "full_rny008_gsm_gru"), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru")):
+        if only and tag not in only:
+            continue
         torch.manual_seed(0)
         m = _RefComposite(arch, tarch, clip_len=4)
         O.randomize_(m, seed=3)
@@ -304,9 +306,10 @@ def gen_full():
             d = m(x)
         for k, v in d.items():
             arrs["eval." + k] = v
-        if tarch == "gru":
+        if True:
             m.train()
-            m._pred_fine._dropout.p = 0.0          # dropout RNG cannot be matched; keep the rest of train mode
+            if tarch == "gru":
+                m._pred_fine._dropout.p = 0.0      # dropout RNG cannot be matched; keep the rest of train mode
             d = m(x)
             for k, v in d.items():
                 arrs["train." + k] = v
@@ -325,7 +328,8 @@ def gen_full():
                 names.append(n)
                 norms.append(p.grad.double().norm().item())
                 if ("conv3D" in n or n.endswith("gsm.bn.weight") or n.startswith("_features.stem")
-                        or n.startswith("_features.s4.b2.se") or n.startswith("_features.s1.b1.conv2")):
+                        or n.startswith("_features.s4.b2.se") or n.startswith("_features.s1.b1.conv2")
+                        or n.startswith("_pred_fine.rnn_layers.0.linear_z") or n.startswith("_pred_fine.fc")):
                     arrs["g." + n] = p.grad
             arrs["grad_names"] = np.array(names)
             arrs["grad_norms"] = np.array(norms, np.float64)
@@ -337,10 +341,12 @@ def gen_full():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_gsm()
-    gen_gated_shift()
-    gen_tsm()
-    gen_heads()
-    gen_step()
-    gen_postproc()
-    gen_full()
+    only = sys.argv[1:]            # optional: names of the composite fixtures to regenerate (skips the module-level ones)
+    if not only:
+        gen_gsm()
+        gen_gated_shift()
+        gen_tsm()
+        gen_heads()
+        gen_step()
+        gen_postproc()
+    gen_full(only)
