@@ -134,23 +134,60 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def call(name, *args):
-    check(getattr(lib(), name)(*args, stream()), name)
-
-
 # ---------------------------------------------------------------- optional per-launch timing (bench.py roofline leg)
-# When TIMING is a list, every stes_gemm launch that runs the 128-wide tile kernel is bracketed by HIP events recorded
-# on the launch stream and appended as (start, end, algorithmic_bytes, flops).
+# When TIMING is a list, every launch is bracketed by HIP events recorded on the launch stream and appended as
+# (kernel, start, end, algorithmic_bytes or None, flops).  `kernel` is the name rocprofv3 shows for the launch.
 TIMING = None
+
+
+def _conv_bytes(a):
+    n, hi, wi, ho, wo, _stride, c = a[-7:]
+    return 2 * c * n * (hi * wi + ho * wo)
+
+
+# entry point -> (kernel name, algorithmic bytes of one call): every operand read once, every result written once
+_KERNEL_OF = {
+    "stes_conv3x3g_fwd": ("conv3x3g_rows_kernel (forward)", _conv_bytes),
+    "stes_conv3x3g_dgrad": ("conv3x3g_rows_kernel / conv3x3g_dgrad2_kernel (input gradient)",
+                            lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
+    "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
+}
+
+
+def _timed(kernel, nbytes, flops, fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    TIMING.append((kernel, e0, e1, nbytes, flops))
+
+
+def call(name, *args):
+    if TIMING is not None:
+        kernel, fb = _KERNEL_OF.get(name, (name.replace("stes_", "") + "_kernel", None))
+        _timed(kernel, fb(args) if fb else None, 0, lambda: check(getattr(lib(), name)(*args, stream()), name))
+        return
+    check(getattr(lib(), name)(*args, stream()), name)
 
 
 def _gemm_work(a, out_bytes):
     m, n, k = a.M, a.N, a.K
-    rows_in = m if not a.a_gate else m
-    byt = rows_in * k * 2 + n * k * 2 + m * n * out_bytes
+    byt = m * k * 2 + n * k * 2 + m * n * out_bytes
     if a.a_gate:
         byt += (m // max(a.gate_group, 1)) * k * 4
+    if a.relu_mask:
+        byt += m * n * 2
     return byt, 2 * m * n * k
+
+
+def _gemm_kernel(a):
+    """Which kernel stes_gemm dispatches to (the rule in stes_gemm.hip)."""
+    stream_ok = (a.N in (32, 64, 128, 160, 320) and a.K % 32 == 0 and a.K <= 320 and not a.c_f32 and a.M >= 8192
+                 and (not a.a_gate or a.N >= 64))
+    if stream_ok:
+        nb = 160 if a.N == 320 else a.N
+        return "gemm_stream_kernel<%d, %d, %s>" % (nb // 16, 8 if nb >= 128 else 4, "true" if a.a_gate else "false")
+    return "gemm_kernel<128>" if a.N > 64 else "gemm_kernel<64>"
 
 
 # ---------------------------------------------------------------- struct-argument entry points
@@ -173,12 +210,9 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
     a.C0, a.ldc0, a.n_split = ptr(C0), ldc0, n_split
     a.M, a.N, a.K, a.out_scale = M, N, K, out_scale
-    if TIMING is not None and N > 64:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
-        e1.record()
-        TIMING.append((e0, e1) + _gemm_work(a, 4 if a.c_f32 else 2))
+    if TIMING is not None:
+        byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
+        _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))
         return
     check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
 
@@ -197,6 +231,10 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
     a.dW, a.lddw, a.dbias = ptr(dW), lddw if lddw is not None else N2, ptr(dbias)
     a.perm_fold = perm_fold
     a.M, a.N1, a.N2 = M, N1, N2
+    if TIMING is not None:
+        _timed("wgrad_kernel<128>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64>", 2 * M * (N1 + N2), 2 * M * N1 * N2,
+               lambda: check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad"))
+        return
     check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")
 
 
@@ -219,11 +257,19 @@ def _bn_bwd_args(D, raw1, M, Cc, *, mul=None, add=None, group=0, act=None, raw2=
 
 def bn_bwd_reduce(D, raw1, M, Cc, sums, **kw):
     a = _bn_bwd_args(D, raw1, M, Cc, sums=sums, **kw)
+    if TIMING is not None:
+        _timed("bn_bwd_reduce_kernel", 2 * M * Cc * (2 + (kw.get("raw2") is not None)), 0,
+               lambda: check(lib().stes_bn_bwd_reduce(C.byref(a), stream()), "stes_bn_bwd_reduce"))
+        return
     check(lib().stes_bn_bwd_reduce(C.byref(a), stream()), "stes_bn_bwd_reduce")
 
 
 def bn_bwd_apply(D, raw1, M, Cc, coef, out, **kw):
     a = _bn_bwd_args(D, raw1, M, Cc, coef=coef, out=out, **kw)
+    if TIMING is not None:
+        # gradient and raw activation read once, result written once (the ReLU-mask source, when given, is raw1 itself)
+        _timed("bn_bwd_apply_kernel", 6 * M * Cc, 0, lambda: check(lib().stes_bn_bwd_apply(C.byref(a), stream()), "stes_bn_bwd_apply"))
+        return
     check(lib().stes_bn_bwd_apply(C.byref(a), stream()), "stes_bn_bwd_apply")
 
 

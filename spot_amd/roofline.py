@@ -50,10 +50,13 @@ def step_fractions(fps_per_gpu):
 
 
 def measure_dominant_kernel(trainer, batch, steps=3):
-    """Roofline of the kernel with the largest share of the step (gemm_kernel<128>: the 1x1 convolutions, their input
-    gradients and the head GEMMs, ~64 launches per step of different shapes).  Every launch of `steps` training steps is
-    bracketed by HIP events on the launch stream; achieved = sum of the launches' algorithmic bytes (A read once, W read
-    once, C written once, SE gate read once) / sum of their durations.  FLOP rate reported beside it."""
+    """Roofline of the kernel with the largest share of the step.  Every launch of `steps` training steps is bracketed by
+    HIP events on the launch stream (spot_amd.lib.TIMING); launches are grouped by kernel, the kernel with the largest
+    summed duration is the dominant one, and achieved = sum of its launches' algorithmic bytes (every operand read once,
+    every result written once) / sum of their durations.  `traffic` (HBM bytes per launch from the PMC counters) comes
+    from the committed counter run of the same command, profiles/pmc_traffic.json, when it holds this kernel."""
+    import json
+    import os
     from . import lib
     x, label, xy = batch
     lib.TIMING = []
@@ -64,12 +67,29 @@ def measure_dominant_kernel(trainer, batch, steps=3):
         recs = lib.TIMING
     finally:
         lib.TIMING = None
-    t = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs) * 1e-3
-    byt = sum(r[2] for r in recs)
-    fl = sum(r[3] for r in recs)
-    n = len(recs)
-    gbs = byt / t / 1e9
-    return {"kernel": "gemm_kernel<128> (stes_gemm, 128-wide tile)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_BPS / 1e9,
-            "unit": "GB/s", "frac": gbs / (HBM_PEAK_BPS / 1e9), "traffic": None,
-            "launches_per_step": n // steps, "avg_launch_us": 1e6 * t / n, "algorithmic_bytes_per_launch": byt / n,
-            "tflops": fl / t / 1e12, "mfma_frac": fl / t / MFMA_PEAK_FLOPS}
+    groups = {}
+    for kernel, e0, e1, byt, fl in recs:
+        g = groups.setdefault(kernel, [0.0, 0, 0, 0, True])
+        g[0] += e0.elapsed_time(e1) * 1e-3
+        g[1] += 1
+        g[2] += byt or 0
+        g[3] += fl
+        g[4] = g[4] and byt is not None
+    total = sum(g[0] for g in groups.values())
+    kernel, (t, n, byt, fl, has_bytes) = max(groups.items(), key=lambda kv: kv[1][0])
+    gbs = byt / t / 1e9 if has_bytes else None
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get(kernel)
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+    out = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+           "frac": gbs / (HBM_PEAK_BPS / 1e9) if gbs else None, "traffic": traffic,
+           "launches_per_step": n // steps, "avg_launch_us": 1e6 * t / n, "algorithmic_bytes_per_launch": byt / n if has_bytes else None,
+           "share_of_step": t / total,
+           "by_kernel_ms_per_step": {k: round(1e3 * v[0] / steps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}}
+    if fl:
+        out["tflops"] = fl / t / 1e12
+        out["mfma_frac"] = fl / t / MFMA_PEAK_FLOPS
+    return out

@@ -36,6 +36,26 @@ def test_tsm_mingru_eval_vs_reference_golden(golden):
         assert r < (2.5e-2 if k == "loc_feat" else 1e-2), (k, r)
 
 
+def test_native_16x9_clip_forward_vs_oracle():
+    """The reference's own inference shape: one clip of 64 frames at 398x224 (odd feature-map sizes 199, 100, 50, 25, 13
+    down the stages), forward only, against the fp32 CPU oracle; time_backward flips the clip before the backbone and the
+    predictions back (reference train_e2e_spatial.py:419-421,449-453)."""
+    from oracle import stes_oracle as O
+    om, m = _pair("rny008_gsm", "gru", clip_len=64, seed=11)
+    x = torch.randn(1, 64, 3, 224, 398, generator=torch.Generator().manual_seed(12))
+    torch.set_num_threads(16)
+    om.eval()
+    with torch.no_grad():
+        od = om(x)
+    m._model.eval()
+    with torch.no_grad():
+        d = m._model(x.cuda())
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].cpu(), od[k])
+        print(k, r)
+        assert r < (2.5e-2 if k == "loc_feat" else 1e-2), (k, r)
+
+
 def test_deeper_gru_eval_vs_oracle():
     from oracle import stes_oracle as O
     om, m = _pair("rny008_gsm", "deeper_gru")
