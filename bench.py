@@ -81,7 +81,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="weight-gradient kernels in program order on the main stream (per-kernel profiles: durations are each kernel's own)")
     args = ap.parse_args()
+    if args.serial:
+        from spot_amd import engine
+        engine.OVERLAP = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +135,7 @@ def main():
         "config": {"workload": "rny008_gsm + BiGRU(L=1) + loc MLP training step (fwd+bwd+AdamW), bf16 storage/fp32 accumulate",
                    "clips_per_gpu": B_PER_GPU, "clip_len": CLIP_LEN, "resolution": RES, "global_batch_clips": world * B_PER_GPU,
                    "parallelism": f"dp{world}", "num_classes": NUM_CLASSES},
-        "final_loss": loss,
+        "final_loss": loss, "overlap_weight_gradients": not args.serial,
     }
     if rank == 0 and world == 1:
         from spot_amd import roofline

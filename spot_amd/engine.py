@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -26,6 +27,9 @@ from .regnet import ConvBnAct
 
 BF = torch.bfloat16
 F32 = torch.float32
+# Weight-gradient kernels run on a side stream beside the input-gradient chain.  Off (STES_SERIAL=1, bench.py --serial, and
+# during the per-kernel roofline pass) they run in program order on the main stream, which gives the same results.
+OVERLAP = os.environ.get("STES_SERIAL", "0") != "1"
 
 
 def _rup(x, m):
@@ -192,7 +196,22 @@ class Block:
         """dZ: gradient w.r.t. this block's output, already masked by (out > 0).  Returns the masked gradient
         w.r.t. the block input."""
         e = self.eng
-        p, g, sc = lib.ptr, e.grad, e.scratch
+        p, g = lib.ptr, e.grad
+        # Weight gradients are off the critical path (nothing in backward reads them): they run on a side stream beside the
+        # input-gradient chain.  Scratch tensors alternate between two sets by block parity, and this block may reuse its set
+        # only once the side stream has finished the block that used it last.
+        par = self.index & 1
+        sc = lambda name, numel, dtype=BF: e.scratch(f"{name}.p{par}", numel, dtype)
+        main = torch.cuda.current_stream()
+        if e.side_done[par] is not None:
+            main.wait_event(e.side_done[par])
+
+        def side(fn):
+            if not OVERLAP:
+                return fn()
+            e.side.wait_stream(main)
+            with torch.cuda.stream(e.side):
+                fn()
         Mi, Mo, cin, cmid, cout = self.Mi, self.Mo, self.cin, self.cmid, self.cout
         HWo = self.Ho * self.Wo
         X, a_src = self.X, self.a_src
@@ -204,8 +223,8 @@ class Block:
         dc3 = sc("dc3", Mo * cout)
         lib.bn_bwd_apply(dZ, self.c3, Mo, cout, bn3.coef, dc3)
         # --- conv3 (1x1): weight and input gradients
-        lib.wgrad(dc3, self.c2, g(self.l3.w), Mo, cout, cmid, scale=bn2.scale, shift=bn2.shift, relu=True, gate=self.segate,
-                  gate_group=HWo)
+        side(lambda: lib.wgrad(dc3, self.c2, g(self.l3.w), Mo, cout, cmid, scale=bn2.scale, shift=bn2.shift, relu=True,
+                               gate=self.segate, gate_group=HWo))
         dA3 = sc("dA3", Mo * cmid)
         lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
         # --- squeeze-excite backward
@@ -227,7 +246,7 @@ class Block:
         lib.bn_bwd_apply(dA3, self.c2, Mo, cmid, bn2.coef, dc2, **kw2)
         # --- grouped 3x3 conv
         geo = (self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
-        lib.call("stes_conv3x3g_wgrad", p(dc2), p(self.c1), p(bn1.scale), p(bn1.shift), p(g(self.w2)), *geo)
+        side(lambda: lib.call("stes_conv3x3g_wgrad", p(dc2), p(self.c1), p(bn1.scale), p(bn1.shift), p(g(self.w2)), *geo))
         dA2 = sc("dA2", Mi * cmid)
         # conv1.bn backward, first half: the input-gradient kernel masks with [bn1(c1) > 0] and accumulates the sums
         lib.call("stes_conv3x3g_dgrad", p(dc2), p(self.wp2_d), p(dA2), p(self.c1), p(bn1.scale), p(bn1.shift), p(bn1.s_dy), p(bn1.s_dyr), *geo)
@@ -236,7 +255,7 @@ class Block:
         lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1)
         # --- conv1 (1x1)
         q0, k0 = (self.G, self.fold) if self.kind == "gsm" else (None, 0)
-        lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold)
+        side(lambda: lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold))
         dY1 = sc("dY1", Mi * cin)
         dG = sc("gsm.dG", Mi * self.fold) if self.kind == "gsm" else None
         lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, ldw=self.l1.Np, C0=dG, ldc0=self.fold, n_split=self.fold)
@@ -245,7 +264,8 @@ class Block:
             gs, bng, geom, Xc, fold = self.gsm, self.bng, self.geom, self.Xc, self.fold
             dpre = sc("gsm.dpre", Mi * 2, F32)
             lib.call("stes_gsm_bwd_gate", p(dG), p(Xc), p(self.gate), p(dpre), C.byref(geom))
-            lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), C.byref(geom))
+            side(lambda: lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)),
+                                  p(g(gs.conv3D.bias)), C.byref(geom)))
             dxbn = sc("gsm.dxbn", Mi * fold)
             lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), C.byref(geom))
             lib.bn_bwd_reduce(dxbn, Xc, Mi, fold, [bng.s_dy, bng.s_dyr])
@@ -263,7 +283,7 @@ class Block:
             dsc = sc("dsc", Mo * cout)
             lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
             rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
-            lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap)
+            side(lambda: lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap))
             Dsc = sc("Dsc", Mo * cin)
             lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
             resid, ms = Dsc, self.stride
@@ -274,6 +294,7 @@ class Block:
         # (for the in-place plain shift of the reference that is the shifted tensor, model/shift.py:55-66)
         lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
                  p(dZp), Mi, cin)
+        e.side_done[par] = e.side.record_event()
         return dZp
 
 
@@ -307,6 +328,8 @@ class Engine:
         lib.lib()
         self.impl, self.dev, self.clip_len = impl, dev, clip_len
         self.casts, self.packs, self.gsm_preps = [], [], []
+        self.side = torch.cuda.Stream(device=dev)      # weight-gradient kernels (see Block.backward)
+        self.side_done = [None, None]
         self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
         self._stats_used = 0
         self._scratch, self._acts, self._pp = {}, {}, {}
@@ -321,6 +344,7 @@ class Engine:
         for sname in ("s1", "s2", "s3", "s4"):
             for bname, blk in getattr(feats, sname).named_children():
                 self.blocks.append(Block(self, blk, f"{sname}.{bname}"))
+                self.blocks[-1].index = len(self.blocks) - 1
         self.feat_dim = self.blocks[-1].cout
         self._build_heads()
         self.weights_dirty = True
@@ -351,6 +375,8 @@ class Engine:
     def scratch(self, name, numel, dtype=BF):
         t = self._scratch.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
+            if t is not None:
+                t.record_stream(self.side)       # the side stream may still be reading the tensor being replaced
             t = torch.empty(numel, dtype=dtype, device=self.dev)
             self._scratch[name] = t
         return t
@@ -699,9 +725,11 @@ class Engine:
         lib.call("stes_pool_bwd", p(dfa), p(dfb), p(self._last_out), p(dZ), N, HWl, Fd)
         if on_ready:
             on_ready(*self.buckets["heads"])
+        main = torch.cuda.current_stream()
         for blk in reversed(self.blocks):
             dZ = blk.backward(dZ)
             if on_ready and blk.name in ("s4.b1", "s3.b1"):
+                main.wait_stream(self.side)          # the bucket's weight gradients are complete
                 on_ready(*self.buckets[blk.name[:2]])
         # stem: dZ is masked by (X0 > 0) already
         bn0 = self.bn0
@@ -711,6 +739,7 @@ class Engine:
         lib.bn_bwd_apply(dZ, self.c0, self.M0, 32, bn0.coef, dc0)
         K = self.stem.K
         lib.wgrad(dc0, self.patches, g(self.stem.w), self.M0, 32, K, ldq=32, lddw=K)
+        main.wait_stream(self.side)                  # every gradient is final from here on (optimizer, next forward)
         if on_ready:
             on_ready(*self.buckets["rest"])
 

@@ -53,13 +53,16 @@ def measure_dominant_kernel(trainer, batch, steps=3):
     """Roofline of the kernel with the largest share of the step.  Every launch of `steps` training steps is bracketed by
     HIP events on the launch stream (spot_amd.lib.TIMING); launches are grouped by kernel, the kernel with the largest
     summed duration is the dominant one, and achieved = sum of its launches' algorithmic bytes (every operand read once,
-    every result written once) / sum of their durations.  `traffic` (HBM bytes per launch from the PMC counters) comes
+    every result written once) / sum of their durations.  During this pass the weight-gradient kernels run on the main
+    stream instead of beside it (engine.OVERLAP off), so that a launch's duration is that kernel's alone and not a share of
+    a GPU it splits with another kernel.  `traffic` (HBM bytes per launch from the PMC counters) comes
     from the committed counter run of the same command, profiles/pmc_traffic.json, when it holds this kernel."""
     import json
     import os
-    from . import lib
+    from . import engine, lib
     x, label, xy = batch
     lib.TIMING = []
+    overlap, engine.OVERLAP = engine.OVERLAP, False
     try:
         for _ in range(steps):
             trainer.step(x, label, xy)
@@ -67,6 +70,7 @@ def measure_dominant_kernel(trainer, batch, steps=3):
         recs = lib.TIMING
     finally:
         lib.TIMING = None
+        engine.OVERLAP = overlap
     groups = {}
     for kernel, e0, e1, byt, fl in recs:
         g = groups.setdefault(kernel, [0.0, 0, 0, 0, True])
