@@ -164,6 +164,13 @@ int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, const float* i
 /* Stem 3x3 stride-2 conv as im2col + stes_gemm: x NCHW fp32 -> patches [N*Ho*Wo][32] bf16,
  * column k = ci*9 + kh*3 + kw (timm stem.conv weight order), columns >= 9*Cin zero.       */
 int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, int W, void* stream);
+/* The same patches from decoded uint8 frames x [B*T_valid][Cin][H][W] (what torchvision.io.read_image returns, reference
+ * dataset/frame.py:29): value = (u/255 - mean[ci]) / std[ci] in fp32, i.e. `.float()/255` (:29) followed by Normalize (:124;
+ * inference_on_mp4.py:523-524) -- the patches equal those of stes_im2col_stem on the loader's fp32 tensor bit for bit.  Clips
+ * of T_valid frames are written as clips of T frames; frames t >= T_valid are the end padding of reference
+ * train_e2e_spatial.py:427-430 (zeros AFTER normalisation).  mean/std: HOST arrays of Cin floats.                          */
+int stes_im2col_stem_u8(const uint8_t* x, uint16_t* patches, const float* mean, const float* std, int B, int T, int T_valid,
+                        int Cin, int H, int W, void* stream);
 
 /* ---------------------------------------------------- temporal shift ----
  * Gated Shift Module, reference model/shift.py:83-161 (_GSM.forward :103-130, GatedShift.forward :157-161).

@@ -596,6 +596,50 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
     }
 }
 
+// The same patches straight from decoded uint8 frames [B*Tv,Cin,H,W]: value = (u/255 - mean[ci]) / std[ci] in fp32, the
+// arithmetic of reference dataset/frame.py:29 followed by :124 (and inference_on_mp4.py:523-524), so the bf16 patches are
+// the ones the fp32 kernel gives on the loader's tensor.  Clips of Tv frames are laid out as clips of T frames: frames
+// t >= Tv are the zero padding of reference train_e2e_spatial.py:427-430, which is zero AFTER normalisation.
+struct StemNorm { float mean[3], stdv[3]; };
+
+__global__ __launch_bounds__(256) void im2col_stem_u8_kernel(const uint8_t* __restrict__ x, bf16* __restrict__ out, StemNorm nm,
+                                                             int B, int T, int Tv, int Cin, int H, int W, int Ho, int Wo) {
+    const long total = (long)B * T * Ho * Wo;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long)gridDim.x * blockDim.x) {
+        const int wo = (int)(m % Wo); const long t0 = m / Wo; const int ho = (int)(t0 % Ho); const long n = t0 / Ho;
+        const int tt = (int)(n % T); const long b = n / T;
+        float f[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) f[k] = 0.f;
+        if (tt < Tv) {
+            const long ns = b * Tv + tt;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                if (ci >= Cin) break;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho * 2 + kh - 1;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int wi = wo * 2 + kw - 1;
+                        if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
+                            const float v = (float)x[((ns * Cin + ci) * H + hi) * (long)W + wi] / 255.0f;
+                            f[ci * 9 + kh * 3 + kw] = (v - nm.mean[ci]) / nm.stdv[ci];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf16)f[c * 8 + i];
+            *reinterpret_cast<bf16x8*>(out + m * 32 + c * 8) = v;
+        }
+    }
+}
+
 }  // namespace
 
 #define S(s) ((hipStream_t)(s))
@@ -754,6 +798,26 @@ extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, con
     const int IW = (TW - 1) * stride + 3;
     hipLaunchKernelGGL(conv3x3g_wgrad_kernel, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)dout, (const bf16*)in, in_scale, in_shift,
                        dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, make_fastdiv(th * tw), make_fastdiv(tw), make_fastdiv(IW));
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_im2col_stem_u8(const uint8_t* x, uint16_t* patches, const float* mean, const float* stdv, int B, int T,
+                                   int T_valid, int Cin, int H, int W, void* stream) {
+    STES_CHECK(x && patches && mean && stdv && B > 0 && T > 0 && T_valid > 0 && T_valid <= T && Cin >= 1 && Cin <= 3 && H > 0 && W > 0,
+               STES_ERR_ARG, "stes_im2col_stem_u8: bad argument");
+    StemNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        nm.mean[c] = c < Cin ? mean[c] : 0.f;
+        nm.stdv[c] = c < Cin ? stdv[c] : 1.f;
+        STES_CHECK(nm.stdv[c] > 0.f, STES_ERR_ARG, "stes_im2col_stem_u8: std must be positive");
+    }
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * T * Ho * Wo;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(im2col_stem_u8_kernel, dim3((int)blocks), dim3(256), 0, S(stream), x, (bf16*)patches, nm, B, T, T_valid, Cin, H, W,
+                       Ho, Wo);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

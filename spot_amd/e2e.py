@@ -35,10 +35,10 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hook, impl):
         eng = impl.engine
-        logits, loc, feat = eng.forward(x, train=impl.training)
+        logits, loc, feat = eng.forward(x, train=impl.training)   # x: fp32 (normalised) or uint8 (decoded) frames
         ctx.impl = impl
         ctx.has_loc = loc is not None
-        outs = (logits.clone(), loc.clone() if loc is not None else x.new_zeros(()), feat.float())
+        outs = (logits.clone(), loc.clone() if loc is not None else logits.new_zeros(()), feat.float())
         return outs
 
     @staticmethod
@@ -140,10 +140,14 @@ class E2EModel(BaseRGBModel):
             if self.time_backward:
                 x = x.flip(1)
             clip_len = true_clip_len
+            pad_T = None
             if self._require_clip_len > 0:
                 assert true_clip_len <= self._require_clip_len, "Expected {}, got {}".format(self._require_clip_len, true_clip_len)
                 if true_clip_len < self._require_clip_len:
-                    x = F.pad(x, (0,) * 7 + (self._require_clip_len - true_clip_len,))
+                    if x.dtype == torch.uint8:
+                        pad_T = self._require_clip_len       # decoded frames: the stem kernel writes the zero frames
+                    else:
+                        x = F.pad(x, (0,) * 7 + (self._require_clip_len - true_clip_len,))
                     clip_len = self._require_clip_len
             eng = self.engine
             if self.training and torch.is_grad_enabled():
@@ -154,7 +158,7 @@ class E2EModel(BaseRGBModel):
                     loc = None
             else:
                 # a padded clip is un-padded before the heads, as the reference does (train_e2e_spatial.py:440-442)
-                logits, loc, feat = eng.forward(x, train=self.training, head_T=true_clip_len)
+                logits, loc, feat = eng.forward(x, train=self.training, head_T=true_clip_len, pad_T=pad_T)
                 logits, feat = logits.clone(), feat.float()
                 loc = loc.clone() if loc is not None else None
             if self.time_backward:
@@ -248,7 +252,7 @@ class E2EModel(BaseRGBModel):
     # ------------------------------------------------------------------ fused training step (HIP loss + backward + AdamW)
     def train_step(self, frame, label, xy, lr, fg_weight=5.0, grad_scale=1.0, ext_denoms=None, optimizer_step=True,
                    after_backward=None, grad_mul=1.0, on_ready=None):
-        """One optimisation step entirely on the device.  frame [B,T,C,H,W] f32, label [B,T] int64, xy [B,T,2] f32.
+        """One optimisation step entirely on the device.  frame [B,T,C,H,W] f32 (normalised) or uint8 (decoded), label [B,T] int64, xy [B,T,2] f32.
         Returns the device tensor {sum, cls, loc, sum of class weights, number of event frames} (no host sync)."""
         m = self._model
         m.train()

@@ -328,6 +328,7 @@ class Engine:
         lib.lib()
         self.impl, self.dev, self.clip_len = impl, dev, clip_len
         self.casts, self.packs, self.gsm_preps = [], [], []
+        self.input_mean, self.input_std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)   # uint8 input only
         self.side = torch.cuda.Stream(device=dev)      # weight-gradient kernels (see Block.backward)
         self.side_done = [None, None]
         self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
@@ -566,14 +567,23 @@ class Engine:
         N, T = N_bb, self.T
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, head_T=None):
-        """x: [B, T, C, H, W] fp32 on the device (T == clip_len when a temporal shift is present).
+    def forward(self, x, train, head_T=None, pad_T=None):
+        """x: [B, T, C, H, W] on the device (T == clip_len when a temporal shift is present): fp32 as the reference loader
+        hands it over (already normalised), or uint8 decoded frames, which the stem normalises itself with `input_mean` /
+        `input_std` (reference dataset/frame.py:16-17,29,124).  A uint8 batch of shorter clips is padded to pad_T frames
+        inside the stem kernel (zero frames after normalisation, reference train_e2e_spatial.py:427-430).
         Returns (logits [B,Th,classes] f32, loc [B,Th,2] f32 | None, feat [B,Th,F] bf16), Th = head_T or T."""
-        B, T, Cin, H, W = x.shape
+        B, Tx, Cin, H, W = x.shape
         if Cin != self.in_chans:
             raise lib.StesError(f"expected {self.in_chans} input channels, got {Cin}")
-        if x.dtype != F32 or not x.is_contiguous():
+        u8 = x.dtype == torch.uint8
+        T = pad_T if (u8 and pad_T) else Tx
+        if T < Tx:
+            raise lib.StesError(f"clips of {Tx} frames cannot be padded to {T}")
+        if not u8 and (x.dtype != F32 or not x.is_contiguous()):
             x = x.contiguous().float()
+        if u8 and not x.is_contiguous():
+            x = x.contiguous()
         self.plan(B, T, H, W, train, head_T)
         if self.weights_dirty or train:
             self.refresh_weights()
@@ -582,7 +592,12 @@ class Engine:
         if train:
             self._stats[:self._stats_used].zero_()
         self._x = x
-        lib.call("stes_im2col_stem", p(x), p(self.patches), N, Cin, H, W)
+        if u8:
+            mean = (C.c_float * 3)(*self.input_mean[:Cin], *([0.0] * (3 - Cin)))
+            std = (C.c_float * 3)(*self.input_std[:Cin], *([1.0] * (3 - Cin)))
+            lib.call("stes_im2col_stem_u8", p(x), p(self.patches), mean, std, B, T, Tx, Cin, H, W)
+        else:
+            lib.call("stes_im2col_stem", p(x), p(self.patches), N, Cin, H, W)
         st = (self.bn0.sum, self.bn0.sumsq) if train else None
         lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
         self.bn0.finalize(self.M0, train)

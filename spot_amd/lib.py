@@ -82,6 +82,7 @@ _SIGS = {
     "stes_conv3x3g_dgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "stes_im2col_stem_u8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gsm_prep": [_P, _P, _I32, _P],
     "stes_gsm_gate": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stes_gsm_shift": [_P, _P, _P, _P, _P],

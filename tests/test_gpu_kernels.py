@@ -112,6 +112,30 @@ def test_im2col_stem():
     assert float(p.float().cpu()[:, 27:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,T,Tv,H,W", [(2, 4, 4, 12, 10), (3, 4, 2, 9, 15), (1, 5, 1, 7, 7)])
+def test_im2col_stem_u8_equals_fp32_path_on_the_loaders_tensor(B, T, Tv, H, W):
+    """Decoded uint8 frames through the stem = `.float()/255` + Normalize (reference dataset/frame.py:29,124) through the
+    fp32 stem, bit for bit, including the clips padded at the end with zero frames (train_e2e_spatial.py:427-430)."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(40)
+    u = torch.randint(0, 256, (B, Tv, 3, H, W), generator=g, dtype=torch.uint8)
+    u[0, 0, :, 0, :3] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    xf = (u.float() / 255 - mean[:, None, None]) / std[:, None, None]
+    xf = F.pad(xf, (0,) * 7 + (T - Tv,))
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    a = torch.full((B * T * Ho * Wo, 32), 7.0, dtype=BF, device="cuda"); b = torch.full_like(a, 9.0)
+    lib.call("stes_im2col_stem", lib.ptr(dev(xf.reshape(B * T, 3, H, W))), lib.ptr(a), B * T, 3, H, W)
+    m3, s3 = (C.c_float * 3)(*mean.tolist()), (C.c_float * 3)(*std.tolist())
+    lib.call("stes_im2col_stem_u8", lib.ptr(dev(u)), lib.ptr(b), m3, s3, B, T, Tv, 3, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu().view(torch.int16), b.cpu().view(torch.int16))
+    if Tv < T:
+        assert float(b.view(B, T, -1)[:, Tv:].float().abs().max()) == 0.0
+    with pytest.raises(lib.StesError):
+        lib.call("stes_im2col_stem_u8", lib.ptr(dev(u)), lib.ptr(b), m3, s3, B, Tv - 1 if Tv > 1 else 0, Tv, 3, H, W)
+
+
 def test_bn_finalize_and_act_residual():
     from spot_amd import lib
     g = torch.Generator().manual_seed(5)

@@ -81,6 +81,38 @@ def test_short_clip_is_padded_then_unpadded_like_reference():
         m.predict(torch.zeros(1, 7, 3, 64, 64))
 
 
+def test_uint8_frames_equal_the_loaders_normalised_tensor():
+    """Decoded uint8 clips at the boundary (`read_image`, reference dataset/frame.py:29) give the predictions of the fp32
+    tensor the reference loader would have built from them (`/255`, Normalize :124), bit for bit in eval mode -- also for
+    a short clip, whose zero frames are padding in normalised space (train_e2e_spatial.py:427-430) -- and train."""
+    import torch.nn.functional as F
+    _, m = _pair("rny008_gsm", "gru")
+    g = torch.Generator().manual_seed(21)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    m._model.eval()
+    for Tv in (4, 3):
+        u = torch.randint(0, 256, (2, Tv, 3, 64, 48), generator=g, dtype=torch.uint8)
+        xf = (u.float() / 255 - mean[:, None, None]) / std[:, None, None]
+        with torch.no_grad():
+            a = {k: v.clone() for k, v in m._model(xf.cuda()).items()}
+            b = m._model(u.cuda())
+        for k in ("cnn_feat", "im_feat", "loc_feat"):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (Tv, k)
+    cls_a, sc_a, loc_a = m.predict(xf)
+    cls_b, sc_b, loc_b = m.predict(u)
+    assert np.array_equal(cls_a, cls_b) and np.array_equal(sc_a, sc_b) and np.array_equal(loc_a, loc_b)
+    # training step from uint8 clips: same loss as from the normalised tensor (the stem patches are identical; the rest of
+    # a training step differs run to run only by the order of its floating-point atomics)
+    u = torch.randint(0, 256, (2, 4, 3, 64, 48), generator=g, dtype=torch.uint8)
+    xf = (u.float() / 255 - mean[:, None, None]) / std[:, None, None]
+    label = torch.randint(0, 7, (2, 4), generator=g).cuda(); xy = torch.rand(2, 4, 2, generator=g).cuda()
+    sd = {k: v.clone() for k, v in m._model.state_dict().items()}
+    la = m.train_step(xf.cuda(), label, xy, lr=0.0).cpu()
+    m._model.load_state_dict(sd)
+    lb = m.train_step(u.cuda(), label, xy, lr=0.0).cpu()
+    assert rel(lb[:3], la[:3]) < 2e-2, (la, lb)
+
+
 def test_sliding_window_events_match_oracle():
     """Long-video path: windows of clip_len frames, last one zero-padded, per-frame scores -> argmax events ->
     score filter 0.15 -> NMS(3).  Event frames and labels must be identical to the CPU oracle's on the same clip."""
