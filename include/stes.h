@@ -134,10 +134,15 @@ int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream);
 
 /* Gradient w.r.t. a bottleneck's input: out = ((c<fold ? dXf : dY) + residual) * (X > 0); the
  * residual is either same-shape (identity shortcut) or the stride-s shortcut conv's input
- * gradient given at output resolution and scattered to the even pixels.                  */
+ * gradient given at output resolution and scattered to the even pixels.
+ * `out` is the gradient at the output of the layer in front; with raw1 [M][C] (the raw conv output under that layer's last
+ * BatchNorm; raw2: the raw output of its shortcut conv, or NULL) the BatchNorm-backward sums of that layer are accumulated on
+ * the way (s_dy += sum out, s_dyr1 += sum out*raw1, s_dyr2 += sum out*raw2; atomics, caller zeroes) and replace its
+ * stes_bn_bwd_reduce pass.                                                                 */
 int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
                        int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
-                       int64_t M, int C, void* stream);
+                       int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
+                       float* s_dyr2, void* stream);
 /* Backward of global average pooling + the last block's ReLU: dZ = (da+db)/HW * (out>0). */
 int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_t* dZ, int N, int HW, int C, void* stream);
 

@@ -348,23 +348,38 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const stes_bn_bwd_arg
 
 // ---------------------------------------------------------------- block input gradient
 // out[m,c] = ((c < fold ? dXf[m,c] : dY[m,c]) + residual) * (X[m,c] > 0)
+// `out` is the gradient at the output of the layer in front of this block; with raw1 (that layer's raw conv output feeding
+// its last BatchNorm; raw2: the raw output of its shortcut conv) the BatchNorm-backward sums of that layer,
+// s_dy[c] += sum out, s_dyr1[c] += sum out*raw1, s_dyr2[c] += sum out*raw2, are taken from the rounded values on their way
+// out, which saves the separate reduction pass its two reads.
+template <bool SUMS>
 __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restrict__ dY, long ldy, const bf16* __restrict__ dXf,
                                                             int fold, const bf16* __restrict__ resid, int ms, int Ho, int Wo,
                                                             int Hi, int Wi, const bf16* __restrict__ X, bf16* __restrict__ out,
-                                                            long M, int C, FastDiv fd_ch, FastDiv fd_hw, FastDiv fd_wi) {
+                                                            long M, int C, FastDiv fd_hw, FastDiv fd_wi,
+                                                            const bf16* __restrict__ raw1, const bf16* __restrict__ raw2,
+                                                            float* __restrict__ s_dy, float* __restrict__ s_dyr1,
+                                                            float* __restrict__ s_dyr2) {
+    extern __shared__ float lds[];     // [3][C] when SUMS
     const int CH = C / 8;
-    const uint32_t total = (uint32_t)(M * CH);
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
-        uint32_t m, chk;
-        fdivmod(i, fd_ch, m, chk);
-        const int c0 = (int)chk * 8;
+    const long gt = (long)blockIdx.x * TPB + threadIdx.x;
+    const long TT = (long)gridDim.x * TPB;          // a multiple of CH (flat_grid): a thread keeps its 8 channels
+    const int c0 = (int)(gt % CH) * 8;
+    const long rstep = TT / CH;
+    float s0[8], s1[8], s2[8];
+    if (SUMS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; }
+        for (int i = threadIdx.x; i < 3 * C; i += TPB) lds[i] = 0.f;
+    }
+    for (long m = gt / CH; m < M; m += rstep) {
         float v[8], x[8];
-        if (c0 < fold) load8b(dXf + (long)m * fold + c0, v); else load8b(dY + (long)m * ldy + c0, v);
+        if (c0 < fold) load8b(dXf + m * fold + c0, v); else load8b(dY + m * ldy + c0, v);
         if (resid) {
             long rm = m; bool ok = true;
             if (ms > 1) {
                 uint32_t n, rem, hi, wi;
-                fdivmod(m, fd_hw, n, rem);
+                fdivmod((uint32_t)m, fd_hw, n, rem);
                 fdivmod(rem, fd_wi, hi, wi);
                 ok = ((hi | wi) & 1) == 0 && (int)(hi >> 1) < Ho && (int)(wi >> 1) < Wo;      // ms == 2
                 rm = ((long)n * Ho + (hi >> 1)) * Wo + (wi >> 1);
@@ -376,10 +391,35 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
         }
-        load8b(X + (long)m * C + c0, x);
+        load8b(X + m * C + c0, x);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = x[k] > 0.f ? v[k] : 0.f;
-        store8b(out + (long)m * C + c0, v);
+        store8b(out + m * C + c0, v);
+        if (SUMS) {
+            float a[8];
+            load8b(raw1 + m * C + c0, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = (float)(bf16)v[k]; s0[k] += v[k]; s1[k] += v[k] * a[k]; }
+            if (raw2) {
+                load8b(raw2 + m * C + c0, a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s2[k] += v[k] * a[k];
+            }
+        }
+    }
+    if (SUMS) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            atomicAdd(&lds[c0 + k], s0[k]); atomicAdd(&lds[C + c0 + k], s1[k]);
+            if (raw2) atomicAdd(&lds[2 * C + c0 + k], s2[k]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += TPB) {
+            atomicAdd(s_dy + i, lds[i]);
+            atomicAdd(s_dyr1 + i, lds[C + i]);
+            if (raw2) atomicAdd(s_dyr2 + i, lds[2 * C + i]);
+        }
     }
 }
 
@@ -523,16 +563,24 @@ extern "C" int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream) {
 
 extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
                                   int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
-                                  int64_t M, int C, void* stream) {
+                                  int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
+                                  float* s_dyr2, void* stream) {
     STES_CHECK(dY && X && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
     STES_CHECK(C % 8 == 0 && fold % 8 == 0 && ldy % 8 == 0 && (fold == 0 || dXf), STES_ERR_ARG, "stes_block_in_grad: alignment");
     STES_CHECK(map_stride == 1 || map_stride == 2, STES_ERR_UNSUPPORTED, "stes_block_in_grad: stride must be 1 or 2");
-    STES_CHECK(M * (C / 8) <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
-    long blocks = (M * (C / 8) + TPB - 1) / TPB;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(block_in_grad_kernel, dim3((int)blocks), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf, fold,
-                       (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, make_fastdiv(C / 8),
-                       make_fastdiv(Hi * Wi), make_fastdiv(Wi));
+    STES_CHECK(M <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
+    STES_CHECK(!raw1 || (s_dy && s_dyr1 && (!raw2 || s_dyr2)), STES_ERR_ARG, "stes_block_in_grad: sums need their outputs");
+    STES_CHECK(raw1 || !raw2, STES_ERR_ARG, "stes_block_in_grad: raw2 without raw1");
+    const int grid = flat_grid(M, C / 8, raw1 ? 1024 : 4096);
+    const FastDiv fhw = make_fastdiv(Hi * Wi), fwi = make_fastdiv(Wi);
+    if (raw1)
+        hipLaunchKernelGGL(block_in_grad_kernel<true>, dim3(grid), dim3(TPB), 3 * C * sizeof(float), S(stream), (const bf16*)dY, (long)ldy,
+                           (const bf16*)dXf, fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C,
+                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2);
+    else
+        hipLaunchKernelGGL(block_in_grad_kernel<false>, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf,
+                           fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, fhw, fwi,
+                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -266,11 +266,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
 // k-steps ahead of their use; the BatchNorm/ReLU/gate prologue runs in registers.  The output tile is staged through a
 // wave-private LDS buffer so that it leaves as whole rows (1 KiB per store instruction) and so that the BatchNorm
 // statistics of the rounded output cost 16 registers per lane (a lane always reads back the same 8 columns).
+#ifndef STES_STREAM_DEPTH
+#define STES_STREAM_DEPTH 4
+#endif
 template <int NI, int WAVES, bool GATE>   // NB = 16*NI columns per workgroup
 __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
                                                                  RowDivs dv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NB = NI * 16, D = 4;
+    constexpr int NB = NI * 16, D = STES_STREAM_DEPTH;
     constexpr int CPR = NB / 8;                 // 16-byte chunks per output row
     constexpr int RPP = 64 / CPR;               // output rows per store pass of a wave
     constexpr int SRS = NB * 2 + 16;            // staging row stride (bytes)
@@ -400,7 +403,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
                     fb[j] = pack8(f);
                 }
             }
-            fetch(d);                               // refill this slot for the step D ahead
+            // refill two slots at a time: consecutive k-steps are the two halves of the same 128-byte lines of A, and issued
+            // back to back the second load finds the line in (or on its way to) the vector L1 instead of fetching it again
+            if (d & 1) { fetch(d - 1); fetch(d); }
             // ---- MFMA: D[n][m] += W[n][k] A[m][k]
 #pragma unroll
             for (int i = 0; i < NI; ++i) {

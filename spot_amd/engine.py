@@ -192,9 +192,10 @@ class Block:
         return self.out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dZ):
+    def backward(self, dZ, sums_done=False):
         """dZ: gradient w.r.t. this block's output, already masked by (out > 0).  Returns the masked gradient
-        w.r.t. the block input."""
+        w.r.t. the block input; the BatchNorm-backward sums of the layer in front of this block (the previous block's
+        conv3/shortcut BatchNorms, or the stem's) are accumulated on the way."""
         e = self.eng
         p, g = lib.ptr, e.grad
         # Weight gradients are off the critical path (nothing in backward reads them): they run on a side stream beside the
@@ -217,8 +218,11 @@ class Block:
         X, a_src = self.X, self.a_src
         bn1, bn2, bn3 = self.bn1, self.bn2, self.bn3
         # --- conv3.bn (+ shortcut bn) backward
-        sums = [bn3.s_dy, bn3.s_dyr] + ([self.bnd.s_dyr] if self.down else [])
-        lib.bn_bwd_reduce(dZ, self.c3, Mo, cout, sums, raw2=self.sc if self.down else None)
+        # (the sums of dZ against conv3's -- and the shortcut conv's -- raw output: taken by the kernel that produced dZ, the
+        # block behind this one, on its way out; only the last block's dZ comes from the pooling backward)
+        if not sums_done:
+            sums = [bn3.s_dy, bn3.s_dyr] + ([self.bnd.s_dyr] if self.down else [])
+            lib.bn_bwd_reduce(dZ, self.c3, Mo, cout, sums, raw2=self.sc if self.down else None)
         bn3.bwd_finalize(Mo)
         dc3 = sc("dc3", Mo * cout)
         lib.bn_bwd_apply(dZ, self.c3, Mo, cout, bn3.coef, dc3)
@@ -292,8 +296,13 @@ class Block:
         dZp = e.scratch_pp("dZ", Mi * cin)
         # the ReLU that produced the block input is masked with the tensor the block actually consumed
         # (for the in-place plain shift of the reference that is the shifted tensor, model/shift.py:55-66)
+        if self.index > 0:
+            prev = e.blocks[self.index - 1]
+            front = (prev.c3, prev.sc if prev.down else None, prev.bn3.s_dy, prev.bn3.s_dyr, prev.bnd.s_dyr if prev.down else None)
+        else:
+            front = (e.c0, None, e.bn0.s_dy, e.bn0.s_dyr, None)
         lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
-                 p(dZp), Mi, cin)
+                 p(dZp), Mi, cin, *[p(t) for t in front])
         e.side_done[par] = e.side.record_event()
         return dZp
 
@@ -742,13 +751,12 @@ class Engine:
             on_ready(*self.buckets["heads"])
         main = torch.cuda.current_stream()
         for blk in reversed(self.blocks):
-            dZ = blk.backward(dZ)
+            dZ = blk.backward(dZ, sums_done=blk is not self.blocks[-1])
             if on_ready and blk.name in ("s4.b1", "s3.b1"):
                 main.wait_stream(self.side)          # the bucket's weight gradients are complete
                 on_ready(*self.buckets[blk.name[:2]])
-        # stem: dZ is masked by (X0 > 0) already
+        # stem: dZ is masked by (X0 > 0) already and its sums against c0 were taken by s1.b1's backward
         bn0 = self.bn0
-        lib.bn_bwd_reduce(dZ, self.c0, self.M0, 32, [bn0.s_dy, bn0.s_dyr])
         bn0.bwd_finalize(self.M0)
         dc0 = sc("dc0", self.M0 * 32)
         lib.bn_bwd_apply(dZ, self.c0, self.M0, 32, bn0.coef, dc0)

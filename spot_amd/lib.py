@@ -75,7 +75,7 @@ _SIGS = {
     "stes_bn_bwd_reduce": [_P, _P],
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
     "stes_bn_bwd_apply": [_P, _P],
-    "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P],
+    "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P],
     "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_pack_conv3x3g": [_P, _P, _P, _I32, _I32, _P],
     "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],

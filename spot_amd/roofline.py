@@ -92,6 +92,10 @@ def measure_dominant_kernel(trainer, batch, steps=3):
            "frac": gbs / (HBM_PEAK_BPS / 1e9) if gbs else None, "traffic": traffic,
            "launches_per_step": n // steps, "avg_launch_us": 1e6 * t / n, "algorithmic_bytes_per_launch": byt / n if has_bytes else None,
            "share_of_step": t / total,
+           # all launches whose byte count is known: what the step moves per the kernels' own accounting, and at what rate
+           "step_kernel_ms": 1e3 * total / steps,
+           "step_algorithmic_gb": sum(g[2] for g in groups.values() if g[4]) / steps / 1e9,
+           "step_ms_with_known_bytes": 1e3 * sum(g[0] for g in groups.values() if g[4]) / steps,
            "by_kernel_ms_per_step": {k: round(1e3 * v[0] / steps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}}
     if fl:
         out["tflops"] = fl / t / 1e12

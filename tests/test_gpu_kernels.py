@@ -287,13 +287,37 @@ def test_block_in_grad_and_pool_bwd():
     ref = (torch.cat([dXf.float(), dY.float()[:, fold:]], 1) + up.view(M, Cc)) * (X.float() > 0)
     out = torch.empty(M, Cc, dtype=BF, device="cuda")
     d = dev
-    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc)
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
+             None, None, None, None, None)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
     ref = (torch.cat([dXf.float(), dY.float()[:, fold:]], 1) + dY.float()) * (X.float() > 0)
-    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc)
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
+             None, None, None, None, None)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
+    # the same with the BatchNorm-backward sums of the layer in front taken on the way out (of the rounded values)
+    plain = out.clone()
+    r1, r2 = bfr(M, Cc, g=g), bfr(M, Cc, g=g)
+    sums = [torch.zeros(Cc, device="cuda") for _ in range(3)]
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
+             lib.ptr(d(r1)), lib.ptr(d(r2)), *[lib.ptr(t) for t in sums])
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)
+    o = out.float().cpu()
+    close(sums[0], o.sum(0), 1e-4, 1e-3)
+    close(sums[1], (o * r1.float()).sum(0), 1e-4, 1e-3)
+    close(sums[2], (o * r2.float()).sum(0), 1e-4, 1e-3)
+    sums = [torch.zeros(Cc, device="cuda") for _ in range(2)]
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
+             lib.ptr(d(r1)), None, lib.ptr(sums[0]), lib.ptr(sums[1]), None)
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    close(sums[0], o.sum(0), 1e-4, 1e-3)
+    close(sums[1], (o * r1.float()).sum(0), 1e-4, 1e-3)
+    with pytest.raises(lib.StesError):
+        lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out),
+                 M, Cc, lib.ptr(d(r1)), None, None, None, None)
     da, db = torch.randn(N, Cc, generator=g), torch.randn(N, Cc, generator=g)
     ref = ((da + db)[:, None] / (Hi * Wi) * (X.float().view(N, Hi * Wi, Cc) > 0)).reshape(M, Cc)
     lib.call("stes_pool_bwd", lib.ptr(d(da)), lib.ptr(d(db)), lib.ptr(d(X)), lib.ptr(out), N, Hi * Wi, Cc)

@@ -1,0 +1,18 @@
+"""One GEMM shape in a loop, for counter passes (debug aid; run on the GPU box):  python tools/bench_one_gemm.py M K N [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from spot_amd import lib
+
+M, K, N = (int(v) for v in sys.argv[1:4])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+torch.cuda.init()
+A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+W = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+Cc = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+for _ in range(reps):
+    lib.gemm(A, W, Cc, M, N, K)
+torch.cuda.synchronize()
