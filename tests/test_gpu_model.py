@@ -187,3 +187,37 @@ def test_fused_train_step_matches_reference_step_semantics():
     # the first AdamW update is lr*sign(g) elementwise; with the gradient noise quantified above (cosine ~0.92 in the
     # deepest layers) ~5 % of the signs differ between two bf16 runs
     assert agree / max(total, 1) > 0.9
+
+
+def test_dp_trainer_over_rccl_world1_matches_plain_step():
+    """The data-parallel trainer on a one-rank RCCL group: global loss denominators, bucketed asynchronous gradient
+    all-reduce issued from inside backward (after the side stream's weight gradients), AdamW after the wait.  With one
+    rank the sums are identities, so two steps must track the plain fused step."""
+    import os
+    import torch.distributed as dist
+    from spot_amd import dp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        _, m1 = build(seed=5)
+        _, m2 = build(seed=5)
+        for m in (m1, m2):
+            m._model._pred_fine._dropout.p = 0.0
+            m._model.engine.drop_p = 0.0
+        g = torch.Generator().manual_seed(12)
+        x = torch.randn(2, 4, 3, 64, 64, generator=g).cuda()
+        label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+        label, xy = label.cuda(), torch.rand(2, 4, 2, generator=g).cuda()
+        trainer = dp.DataParallelTrainer(m2, dist, lr=1e-3)
+        for _ in range(2):
+            a = m1.train_step(x, label, xy, lr=1e-3).cpu()
+            b = trainer.step(x, label, xy).cpu()
+            np.testing.assert_allclose(a[:3].numpy(), b[:3].numpy(), rtol=3e-2)
+            assert a[3:].tolist() == b[3:].tolist()             # class-weight sum and event count: exact
+        g1, g2 = m1._model.engine.flat_grad.double(), m2._model.engine.flat_grad.double()
+        cos = float((g1 * g2).sum() / (g1.norm() * g2.norm()))
+        print("gradient cosine, plain vs data-parallel step:", cos)
+        assert cos > 0.9
+    finally:
+        dist.destroy_process_group()
