@@ -1,0 +1,247 @@
+"""Training driver around the hot path: the counterpart of the reference's `main` (train_e2e_spatial.py:1034-1236) for
+the parts that touch the model -- optimizer, warm-up + cosine schedule, epochs, checkpoints, resume -- with the reference's
+flag names, file names and file contents, so a `save_dir` written here is read by the reference and the other way round.
+
+What is NOT here is the reference's frame reader and augmentation stack (dataset/frame.py): at >10^4 frames/s a GPU is fed
+from pre-decoded clips.  `frame_dir` holds shards `train_*.npz` / `val_*.npz` with
+
+    frame uint8 [n, clip_len, 3, H, W]   decoded RGB frames (the stem normalises them on the GPU)
+    label int64 [n, clip_len]            0 = background
+    xy    float32 [n, clip_len, 2]       event location in [0, 1]
+
+or is the literal string `synthetic[:n_clips]`.  Validation mAP needs the dataset JSON files and the reference's
+scoring code around this path; this driver selects the best epoch by validation loss (`--criterion loss`).
+
+    python -m spot_amd.train DATASET FRAME_DIR -m rny008_gsm -t gru --clip_len 64 --batch_size 16 --predict_location -s DIR
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import ChainedScheduler, CosineAnnealingLR, LinearLR
+
+FEATURE_ARCHS = ["rny008", "rny008_tsm", "rny008_gsm"]
+
+
+def get_args(argv=None):
+    """The reference's flags (train_e2e_spatial.py:45-177) that reach the model or the training loop."""
+    p = argparse.ArgumentParser()
+    p.add_argument("dataset", type=str)
+    p.add_argument("frame_dir", type=str, help="directory of pre-decoded clip shards, or synthetic[:n_clips]")
+    p.add_argument("--modality", type=str, choices=["rgb"], default="rgb")
+    p.add_argument("-m", "--feature_arch", type=str, required=True, choices=FEATURE_ARCHS)
+    p.add_argument("-t", "--temporal_arch", type=str, default="gru")
+    p.add_argument("-p", "--pred_loc_arch", type=str, default="mlp")
+    p.add_argument("--clip_len", type=int, default=100)
+    p.add_argument("--crop_dim", type=int, default=224)
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("-ag", "--acc_grad_iter", type=int, default=1)
+    p.add_argument("--warm_up_epochs", type=int, default=3)
+    p.add_argument("--num_epochs", type=int, default=50)
+    p.add_argument("-lr", "--learning_rate", type=float, default=0.001)
+    p.add_argument("-s", "--save_dir", type=str, required=True)
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--predict_location", action="store_true")
+    p.add_argument("--criterion", choices=["map", "loss"], default="loss")
+    p.add_argument("--time_backward", action="store_true")
+    p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
+    p.add_argument("--device", type=str, default="cuda")
+    return p.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------- data
+class ClipShards:
+    """Batches in the format the reference's loaders hand to `E2EModel.epoch` (train_e2e_spatial.py:537-547): a dict with
+    `frame`, `label`, `xy`.  Frames stay uint8 until the stem kernel."""
+
+    def __init__(self, files, batch_size):
+        self.files, self.batch_size = sorted(files), batch_size
+        self._n = []
+        for f in self.files:
+            with np.load(f) as z:
+                self._n.append(int(z["label"].shape[0]))
+
+    def __len__(self):
+        return sum(n // self.batch_size for n in self._n)
+
+    def __iter__(self):
+        for f in self.files:
+            with np.load(f) as z:
+                frame, label, xy = z["frame"], z["label"], z["xy"]
+            for i in range(0, label.shape[0] - self.batch_size + 1, self.batch_size):
+                s = slice(i, i + self.batch_size)
+                yield {"frame": torch.from_numpy(frame[s]), "label": torch.from_numpy(label[s]).long(),
+                       "xy": torch.from_numpy(xy[s]).float()}
+
+
+class SyntheticClips:
+    """Random uint8 clips with the foreground rate of the reference's dataset (6137 events in 251110 frames)."""
+
+    def __init__(self, n_clips, batch_size, clip_len, dim, num_classes, seed):
+        self.n, self.bs, self.T, self.dim, self.nc, self.seed = n_clips, batch_size, clip_len, dim, num_classes, seed
+
+    def __len__(self):
+        return self.n // self.bs
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(len(self)):
+            fg = torch.rand(self.bs, self.T, generator=g) < 0.0244
+            yield {"frame": torch.randint(0, 256, (self.bs, self.T, 3, self.dim, self.dim), generator=g, dtype=torch.uint8),
+                   "label": fg.long() * torch.randint(1, self.nc, (self.bs, self.T), generator=g),
+                   "xy": torch.rand(self.bs, self.T, 2, generator=g)}
+
+
+def get_loaders(args, num_classes):
+    bs = args.batch_size // args.acc_grad_iter
+    if args.frame_dir.startswith("synthetic"):
+        n = int(args.frame_dir.split(":")[1]) if ":" in args.frame_dir else 4 * args.batch_size
+        mk = lambda seed, k: SyntheticClips(k, bs, args.clip_len, args.crop_dim, num_classes, seed)
+        return mk(0, n), mk(1, max(bs, n // 4))
+    tr, va = (glob.glob(os.path.join(args.frame_dir, f"{s}_*.npz")) for s in ("train", "val"))
+    if not tr or not va:
+        raise FileNotFoundError(f"no train_*.npz / val_*.npz shards in {args.frame_dir}")
+    return ClipShards(tr, bs), ClipShards(va, bs)
+
+
+def load_classes(args):
+    """reference util/dataset.py load_classes: one class name per line -> index from 1 (0 is background)."""
+    f = os.path.join("data", args.dataset, "class.txt")
+    if os.path.exists(f):
+        with open(f) as fp:
+            names = [l.strip() for l in fp if l.strip()]
+        return {n: i + 1 for i, n in enumerate(names)}
+    if args.num_classes is None:
+        raise FileNotFoundError(f"{f} not found and --num_classes not given")
+    return {f"class{i + 1}": i + 1 for i in range(args.num_classes)}
+
+
+# ------------------------------------------------------------------------------------------------- schedule, save, resume
+def get_lr_scheduler(args, optimizer, num_steps_per_epoch):
+    """reference train_e2e_spatial.py:1014-1031: linear warm-up from 1 % chained with cosine annealing, stepped per iteration."""
+    cosine_epochs = args.num_epochs - args.warm_up_epochs
+    print("Using Linear Warmup ({}) + Cosine Annealing LR ({})".format(args.warm_up_epochs, cosine_epochs))
+    return args.num_epochs, ChainedScheduler([
+        LinearLR(optimizer, start_factor=0.01, end_factor=1.0, total_iters=args.warm_up_epochs * num_steps_per_epoch),
+        CosineAnnealingLR(optimizer, num_steps_per_epoch * cosine_epochs)])
+
+
+def get_last_epoch(save_dir):
+    """reference train_e2e_spatial.py:830-838"""
+    last = -1
+    for name in os.listdir(save_dir):
+        if name.startswith("optim_"):
+            last = max(last, int(os.path.splitext(name)[0].split("optim_")[1]))
+    return last
+
+
+def get_best_epoch_and_history(save_dir, criterion):
+    """reference train_e2e_spatial.py:841-849"""
+    with open(os.path.join(save_dir, "loss.json")) as fp:
+        data = json.load(fp)
+    if criterion == "map":
+        best = max(data, key=lambda x: x["val_mAP"]); key = "val_mAP"
+    else:
+        best = min(data, key=lambda x: x["val"]); key = "val"
+    return data, best["epoch"], best[key]
+
+
+def load_from_save(args, model, optimizer, scaler, lr_scheduler):
+    """reference train_e2e_spatial.py:936-981: the newest checkpoint without its `_fc_out` tensors (a changed class list
+    changes their shape) loaded non-strictly; optimizer/scaler/scheduler state only on --resume and only when nothing was
+    filtered; a state that does not fit resets the optimizer with a warning instead of failing."""
+    assert args.save_dir is not None
+    epoch = get_last_epoch(args.save_dir)
+    print("Loading from epoch {}".format(epoch))
+    checkpoint = torch.load(os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(epoch)), map_location="cpu", weights_only=True)
+    filtered = {k: v for k, v in checkpoint.items() if "_fc_out" not in k}
+    filter_applied = len(filtered) < len(checkpoint)
+    if filter_applied:
+        print(f"Loading checkpoint with strict=False (filtered {len(checkpoint) - len(filtered)} keys containing '_fc_out')")
+    else:
+        print("Loading checkpoint with strict=False")
+    model.load(filtered, strict=False)
+    if args.resume:
+        if filter_applied:
+            print("Skipping optimizer/scheduler load due to model architecture change (keys filtered).")
+        else:
+            try:
+                opt_data = torch.load(os.path.join(args.save_dir, "optim_{:03d}.pt".format(epoch)), map_location="cpu", weights_only=True)
+                optimizer.load_state_dict(opt_data["optimizer_state_dict"])
+                if scaler is not None:
+                    scaler.load_state_dict(opt_data["scaler_state_dict"])
+                lr_scheduler.load_state_dict(opt_data["lr_state_dict"])
+            except Exception as e:       # noqa: BLE001 -- the reference catches everything here
+                print(f"Warning: Failed to load optimizer/scheduler state (likely due to model architecture change). Resetting optimizer. Error: {e}")
+    losses, best_epoch, best_criterion = get_best_epoch_and_history(args.save_dir, args.criterion)
+    return epoch, losses, best_epoch, best_criterion
+
+
+def store_config(file_path, args, num_epochs, classes):
+    """reference train_e2e_spatial.py:984-1011 (the keys inference reads back: num_classes, archs, clip_len, crop_dim)."""
+    config = {"dataset": args.dataset, "num_classes": len(classes), "modality": args.modality, "feature_arch": args.feature_arch,
+              "temporal_arch": args.temporal_arch, "clip_len": args.clip_len, "batch_size": args.batch_size, "crop_dim": args.crop_dim,
+              "num_epochs": num_epochs, "warm_up_epochs": args.warm_up_epochs, "learning_rate": args.learning_rate,
+              "predict_location": args.predict_location, "pred_loc_arch": args.pred_loc_arch, "time_backward": args.time_backward,
+              "acc_grad_iter": args.acc_grad_iter, "criterion": args.criterion}
+    with open(file_path, "w") as fp:
+        json.dump(config, fp, indent=2, sort_keys=True)
+
+
+def clear_files(dir_name, re_str):
+    for name in os.listdir(dir_name):
+        if re.match(re_str, name):
+            os.remove(os.path.join(dir_name, name))
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
+def main(args):
+    from .e2e import E2EModel
+    if args.criterion == "map":
+        raise NotImplementedError("validation mAP needs the dataset JSONs and scoring code around this path; use --criterion loss")
+    assert args.batch_size % args.acc_grad_iter == 0
+    classes = load_classes(args)
+    model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
+                     device=args.device, predict_location=args.predict_location, pred_loc_arch=args.pred_loc_arch,
+                     time_backward=args.time_backward)
+    train_loader, val_loader = get_loaders(args, len(classes) + 1)
+    optimizer, scaler = model.get_optimizer({"lr": args.learning_rate})
+    num_steps_per_epoch = len(train_loader) // args.acc_grad_iter
+    num_epochs, lr_scheduler = get_lr_scheduler(args, optimizer, num_steps_per_epoch)
+    losses, best_epoch, best_criterion = [], None, float("inf")
+    epoch = 0
+    if args.resume:
+        epoch, losses, best_epoch, best_criterion = load_from_save(args, model, optimizer, scaler, lr_scheduler)
+        epoch += 1
+    os.makedirs(args.save_dir, exist_ok=True)
+    for epoch in range(epoch, num_epochs):
+        train_loss = model.epoch(train_loader, optimizer, scaler, lr_scheduler=lr_scheduler, acc_grad_iter=args.acc_grad_iter)
+        val_loss = model.epoch(val_loader, acc_grad_iter=args.acc_grad_iter)
+        print("Epoch {}: train cls {:.5f} loc {:.5f} sum {:.5f} | val cls {:.5f} loc {:.5f} sum {:.5f}".format(
+            epoch, train_loss["cls"], train_loss["loc"], train_loss["sum"], val_loss["cls"], val_loss["loc"], val_loss["sum"]))
+        if val_loss["sum"] < best_criterion:
+            best_criterion, best_epoch = val_loss["sum"], epoch
+            print("New best epoch!")
+        losses.append({"epoch": epoch, "train": train_loss["sum"], "val": val_loss["sum"], "val_mAP": 0})
+        with open(os.path.join(args.save_dir, "loss.json"), "w") as fp:
+            json.dump(losses, fp, indent=2, sort_keys=True)
+        torch.save(model.state_dict(), os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(epoch)))
+        clear_files(args.save_dir, r"optim_\d+\.pt")
+        torch.save({"optimizer_state_dict": optimizer.state_dict(),
+                    "scaler_state_dict": scaler.state_dict() if scaler is not None else {},
+                    "lr_state_dict": lr_scheduler.state_dict()}, os.path.join(args.save_dir, "optim_{:03d}.pt".format(epoch)))
+        store_config(os.path.join(args.save_dir, "config.json"), args, num_epochs, classes)
+    print("Best epoch: {}\n".format(best_epoch))
+    if best_epoch is not None:
+        model.load(torch.load(os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(best_epoch)), map_location="cpu", weights_only=True))
+    return model, losses, best_epoch
+
+
+if __name__ == "__main__":
+    main(get_args())

@@ -206,3 +206,37 @@ def test_full_size_properties():
     assert np.isfinite(l1).all() and np.isfinite(l2).all()
     assert not torch.equal(w0, eng.flat) and bool(torch.isfinite(eng.flat).all())
     assert l2[0] < l1[0], (l1, l2)                                   # (4)
+
+
+def test_train_driver_runs_checkpoints_and_resumes(tmp_path):
+    """spot_amd.train (counterpart of the reference's main, train_e2e_spatial.py:1034-1236) on synthetic uint8 clips: two
+    epochs through E2EModel.epoch with a stock AdamW + chained schedule, the reference's files in save_dir, then --resume
+    for a third epoch; a shard directory loads like the synthetic source."""
+    import json
+    import os
+    from spot_amd import train as TR
+    base = ["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "gru", "--clip_len", "4", "--crop_dim", "64", "--batch_size", "2",
+            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6"]
+    model, losses, best = TR.main(TR.get_args(base + ["--num_epochs", "2"]))
+    names = set(os.listdir(tmp_path))
+    assert {"checkpoint_000.pt", "checkpoint_001.pt", "optim_001.pt", "loss.json", "config.json"} <= names and "optim_000.pt" not in names
+    assert [l["epoch"] for l in losses] == [0, 1] and all(np.isfinite(l["train"]) and np.isfinite(l["val"]) for l in losses)
+    sd = torch.load(tmp_path / "checkpoint_001.pt", weights_only=True)
+    assert set(sd) == set(model.state_dict())
+    model2, losses2, _ = TR.main(TR.get_args(base + ["--num_epochs", "3", "--resume"]))
+    assert [l["epoch"] for l in losses2] == [0, 1, 2] and np.isfinite(losses2[2]["train"])
+    # resumed from checkpoint_001 (minus the `_fc_out` tensors, which the reference always drops): a backbone tensor moved
+    # on from the saved value by one more epoch of small steps, not from a fresh initialisation
+    k = "_features.s1.b1.conv2.conv.weight"
+    moved = (model2.state_dict()[k].cpu() - sd[k].cpu()).abs().max()
+    assert 0 < float(moved) < 0.05, moved
+    assert json.load(open(tmp_path / "config.json"))["num_classes"] == 6
+    # the same data from a shard directory
+    shard_dir = tmp_path / "shards"
+    os.makedirs(shard_dir)
+    for split, seed in (("train", 0), ("val", 1)):
+        b = list(TR.SyntheticClips(4, 4, 4, 64, 7, seed))[0]
+        np.savez(shard_dir / f"{split}_000.npz", frame=b["frame"].numpy(), label=b["label"].numpy(), xy=b["xy"].numpy())
+    args = TR.get_args(["ds", str(shard_dir)] + base[2:-4] + ["-s", str(tmp_path / "run2"), "--num_classes", "6", "--num_epochs", "2"])
+    _, losses3, _ = TR.main(args)
+    assert len(losses3) == 2 and np.isfinite(losses3[1]["val"])

@@ -1,5 +1,6 @@
 """CPU tests: host-side logic, the C-ABI surface, the data-parallel bucketing over gloo (world_size 2)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -131,3 +132,45 @@ def test_dp_bucketed_allreduce_and_global_denominators_gloo():
         assert torch.equal(flat, want)
         # 16 frames, 4 events: weights 12*1 + 4*5 = 32
         assert den.tolist() == [32.0, 4.0]
+
+
+def test_train_driver_schedule_and_resume_rules(tmp_path):
+    """spot_amd.train mirrors the reference's schedule (train_e2e_spatial.py:1014-1031) and resume rules (:936-981):
+    `_fc_out` tensors are dropped and the rest loaded non-strictly; optimizer state is restored only on --resume and only
+    when nothing was dropped."""
+    from spot_amd import train as TR
+    args = TR.get_args(["ds", "synthetic:8", "-m", "rny008_gsm", "-s", str(tmp_path), "--num_epochs", "5", "--warm_up_epochs", "2",
+                        "--num_classes", "6", "--resume"])
+    w = torch.nn.Parameter(torch.zeros(3))
+    w.grad = torch.ones(3)
+    opt = torch.optim.AdamW([{"params": w, "lr": 1e-3}])
+    n, sched = TR.get_lr_scheduler(args, opt, num_steps_per_epoch=10)
+    lrs = []
+    for _ in range(50):
+        lrs.append(opt.param_groups[0]["lr"]); opt.step(); sched.step()
+    # both factors act from step 0 (ChainedScheduler): 1 % start; the cosine, whose period is the 30 post-warm-up steps,
+    # reaches its zero at step 30 and turns up again
+    assert n == 5 and abs(lrs[0] - 1e-5) < 1e-12 and max(lrs) < 1e-3
+    assert int(np.argmin(lrs[1:])) + 1 == 30 and lrs[30] < 1e-9 and lrs[31] > lrs[30]
+
+    class Stub:
+        def load(self, sd, strict=True):
+            self.sd, self.strict = sd, strict
+    sd = {"_features.stem.conv.weight": torch.ones(2), "_pred_fine._fc_out._fc_out.weight": torch.ones(7, 4), "_pred_fine._fc_out._fc_out.bias": torch.ones(7)}
+    torch.save(sd, tmp_path / "checkpoint_003.pt")
+    opt.step()
+    state = {"optimizer_state_dict": opt.state_dict(), "scaler_state_dict": {}, "lr_state_dict": sched.state_dict()}
+    torch.save(state, tmp_path / "optim_003.pt")
+    with open(tmp_path / "loss.json", "w") as fp:
+        json.dump([{"epoch": 2, "train": 1.0, "val": 0.7, "val_mAP": 0}, {"epoch": 3, "train": 0.9, "val": 0.8, "val_mAP": 0}], fp)
+    assert TR.get_last_epoch(str(tmp_path)) == 3
+    m = Stub()
+    opt2 = torch.optim.AdamW([{"params": torch.nn.Parameter(torch.zeros(3)), "lr": 1e-3}])
+    _, sched2 = TR.get_lr_scheduler(args, opt2, 10)
+    epoch, losses, best_epoch, best = TR.load_from_save(args, m, opt2, None, sched2)
+    assert (epoch, best_epoch, best, len(losses)) == (3, 2, 0.7, 2)
+    assert m.strict is False and list(m.sd) == ["_features.stem.conv.weight"]
+    assert len(opt2.state_dict()["state"]) == 0                                      # filtered => optimizer state not restored
+    torch.save({k: v for k, v in sd.items() if "_fc_out" not in k}, tmp_path / "checkpoint_003.pt")
+    TR.load_from_save(args, m, opt2, None, sched2)
+    assert len(opt2.state_dict()["state"]) == 1 and sched2.state_dict()["_schedulers"][0]["last_epoch"] == 50
