@@ -62,13 +62,16 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
 #endif
 }
 
-template <int V, int WB>   // V: channels per LDS read (4 when half == 4, else 8); WB: outputs per thread along w (4 or 1)
+// HALF: channels per group as a compile-time constant (0: read from the geometry).  With it the channel loop unrolls, the
+// LDS reads and the scalar weight loads of a whole (kt, kh) tap row are issued together and waited for once -- at one or
+// two waves per SIMD the kernel is bound by exactly those latencies.
+template <int V, int WB, int HALF>   // V: channels per LDS read (4 when half == 4, else 8); WB: outputs per thread along w (4 or 1)
 __global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ Xc, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const uint32_t* __restrict__ wt,
                                                        const float* __restrict__ b3d, float* __restrict__ gate, Geom gm, GateTile gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MAXI = 8;
-    const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
+    const int fold = gm.fold, half = HALF ? HALF : (fold >> 1), nch = fold >> 3;
     const int W = gm.W, H = gm.H, T = gm.T, W2 = W + 2, rows = gt.TH + 2;
     const int h0 = blockIdx.x * gt.TH, t0 = blockIdx.y * gt.TSEG, b = blockIdx.z;
     const int t1 = (t0 + gt.TSEG < T) ? t0 + gt.TSEG : T;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ 
                 for (int kh = 0; kh < 3; ++kh) {
                     const unsigned char* rowp = sl + (((int)hr + kh) * W2 + w0) * pstride + grp * half * 2;
                     const uint32_t* wrow = wg + (((kt * 3 + kh) * 3) * half) / 2;
-                    for (int c = 0; c < half; c += V) {
+                    auto chunk = [&](int c) {
                         if (WB == 4) {
                             xvec x[6];
 #pragma unroll
@@ -174,6 +177,12 @@ __global__ __launch_bounds__(256) void gsm_gate_kernel(const bf16* __restrict__ 
                                 }
                             }
                         }
+                    };
+                    if (HALF > 0) {
+#pragma unroll
+                        for (int c = 0; c < HALF; c += V) chunk(c);
+                    } else {
+                        for (int c = 0; c < half; c += V) chunk(c);
                     }
                 }
             }
@@ -258,6 +267,54 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restric
         }
         const float gt = gate[i];
         dpre[i] = acc * (1.f - gt * gt);
+    }
+}
+
+// The same for groups of 16 channels and more (half % 8 == 0, half >= 16): thread per 16-byte chunk, so that a wave's loads are
+// one contiguous run of rows instead of 64 runs of `half` channels; the chunk sums of a (row, group) meet in LDS.
+__global__ __launch_bounds__(256) void gsm_bwd_gate_rows_kernel(const bf16* __restrict__ dG, const bf16* __restrict__ Xc,
+                                                                const float* __restrict__ gate, float* __restrict__ dpre, Geom gm,
+                                                                int rows_per_block, FastDiv fd_nch) {
+    __shared__ float part[256];
+    const int fold = gm.fold, nch = fold >> 3, hch = nch >> 1;
+    const long plane = (long)gm.H * gm.W;
+    const long n_blocks = (gm.M + rows_per_block - 1) / rows_per_block;
+    uint32_t r, ch;
+    fdivmod((uint32_t)threadIdx.x, fd_nch, r, ch);
+    const bool active = (int)r < rows_per_block;
+    const int g = (int)ch >= hch;
+    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const long m = blk * rows_per_block + r;
+        float acc = 0.f;
+        if (active && m < gm.M) {
+            const int t = frame_of((uint32_t)m, gm);
+            const int tp = g == 0 ? t - 1 : t + 1;             // frame whose output used y[t]
+            const long off = m * fold + (long)ch * 8;
+            float x[8], d0[8];
+            load8b(Xc + off, x); load8b(dG + off, d0);
+            if (tp >= 0 && tp < gm.T) {
+                float d1[8];
+                load8b(dG + off + (g == 0 ? -plane : plane) * fold, d1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += (d1[k] - d0[k]) * x[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc -= d0[k] * x[k];
+            }
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < rows_per_block * 2) {
+            const int rr = threadIdx.x >> 1, gg = threadIdx.x & 1;
+            const long mm = blk * rows_per_block + rr;
+            if (mm < gm.M) {
+                float sum = 0.f;
+                for (int c = 0; c < hch; ++c) sum += part[rr * nch + gg * hch + c];
+                const float gt = gate[mm * 2 + gg];
+                dpre[mm * 2 + gg] = sum * (1.f - gt * gt);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -612,40 +669,50 @@ extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float
     const int nch = gm.fold / 8;
     GateTile gt;
     gt.PS = (nch >= 4 && nch % 2 == 0) ? nch + 1 : nch;         // odd 16-byte stride: conflict-free ds_read_b128 across positions
-    const int wb = gm.W >= 28 ? 4 : 1, spr = stes_div_up(gm.W, wb);
+    const int wb = 1, spr = stes_div_up(gm.W, wb);
     // + 4 positions: the last strip of a ragged row may read (and discard) past the tile's end
     auto slot = [&](int t) { return (size_t)((t + 2) * (gm.W + 2) + 4) * gt.PS * 16; };
-    auto fits = [&](int t) { return 3 * slot(t) <= 72 * 1024 && (long)(t + 2) * (gm.W + 2) * nch <= 8 * 256; };
-    // rows per tile: best product of thread utilisation (128 threads per group walk TH*spr strips), row-tile
-    // quantisation and halo overhead
+    auto lds_of = [&](int t) { return 3 * slot(t) + (size_t)gm.fold * 2 * sizeof(float); };
+    auto fits = [&](int t) { return lds_of(t) <= 150 * 1024 && (long)(t + 2) * (gm.W + 2) * nch <= 8 * 256; };
+    // rows per tile: best product of thread utilisation (128 threads per group walk TH*spr strips), row-tile quantisation,
+    // halo overhead and residency -- with one or two waves per SIMD the kernel waits on LDS and scalar-load latency, so
+    // the workgroups that fit a CU's 160 KiB of LDS count (up to four)
     int th = 1; double best = -1.0;
     for (int t = 1; t <= gm.H; ++t) {
         if (!fits(t)) break;
         const int strips = t * spr;
-        const double eff = (double)strips / (128.0 * stes_div_up(strips, 128)) * gm.H / ((double)t * stes_div_up(gm.H, t)) * t / (t + 2.0);
+        const int resident = (int)std::min<size_t>(4, 160 * 1024 / lds_of(t));
+        const double quant = gm.H / ((double)t * stes_div_up(gm.H, t));       // a ragged last tile costs a whole workgroup
+        const double eff = (double)strips / (128.0 * stes_div_up(strips, 128)) * quant * quant * quant * quant * t / (t + 2.0) *
+                           resident / 4.0;
         if (eff > best) { best = eff; th = t; }
     }
     STES_CHECK(fits(th), STES_ERR_UNSUPPORTED, "stes_gsm_gate: image row too wide for the LDS tile");
     const int rt = stes_div_up(gm.H, th);
     int tseg = gm.T;
-    while (tseg > 4 && (long)rt * gm.B * stes_div_up(gm.T, tseg) < 512) tseg = (tseg + 1) / 2;
+    while (tseg > 4 && (long)rt * gm.B * stes_div_up(gm.T, tseg) < 2048) tseg = (tseg + 1) / 2;
     gt.TH = th; gt.TSEG = tseg;
     gt.fd_nch = make_fastdiv(nch); gt.fd_W2 = make_fastdiv(gm.W + 2); gt.fd_spr = make_fastdiv(spr);
-    const size_t lds = 3 * slot(th) + (size_t)gm.fold * 2 * sizeof(float);
+    const size_t lds = lds_of(th);
     const dim3 grid(rt, stes_div_up(gm.T, tseg), gm.B);
-    static const bool big_lds = [] {     // tiles beyond the default 64 KiB dynamic-LDS limit
-        bool ok = true;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        return ok;
-    }();
-    STES_CHECK(big_lds || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_gate: cannot raise the dynamic LDS limit");
-#define LAUNCH_GATE(V, WB) hipLaunchKernelGGL((gsm_gate_kernel<V, WB>), grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, (const uint32_t*)wt, b3d, gate, gm, gt)
-    if (gm.fold == 8) { if (wb == 4) LAUNCH_GATE(4, 4); else LAUNCH_GATE(4, 1); }
-    else { if (wb == 4) LAUNCH_GATE(8, 4); else LAUNCH_GATE(8, 1); }
-#undef LAUNCH_GATE
+    const int half = gm.fold / 2;
+#define GATE_CASE(V, WB, HF)                                                                                                       \
+    do {                                                                                                                           \
+        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_gate_kernel<V, WB, HF>),                \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;     \
+        STES_CHECK(big_lds || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_gate: cannot raise the dynamic LDS limit");        \
+        hipLaunchKernelGGL((gsm_gate_kernel<V, WB, HF>), grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift,           \
+                           (const uint32_t*)wt, b3d, gate, gm, gt);                                                                \
+    } while (0)
+    // the channel counts of RegNet-Y 800MF's gated shifts get their own instantiation, anything else the generic loop
+    if (gm.fold == 8) { if (wb == 4) GATE_CASE(4, 4, 4); else GATE_CASE(4, 1, 4); }
+    else if (wb == 4) {
+        if (half == 8) GATE_CASE(8, 4, 8); else if (half == 16) GATE_CASE(8, 4, 16); else GATE_CASE(8, 4, 0);
+    } else {
+        if (half == 8) GATE_CASE(8, 1, 8); else if (half == 16) GATE_CASE(8, 1, 16); else if (half == 40) GATE_CASE(8, 1, 40); else if (half == 96) GATE_CASE(8, 1, 96);
+        else GATE_CASE(8, 1, 0);
+    }
+#undef GATE_CASE
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -667,6 +734,15 @@ extern "C" int stes_gsm_bwd_gate(const uint16_t* dG, const uint16_t* Xc, const f
     int rc = check_geom(g); if (rc) return rc;
     STES_CHECK(dG && Xc && gate && dpre, STES_ERR_ARG, "stes_gsm_bwd_gate: bad argument");
     const Geom gm = to_geom(g);
+    const int nch = gm.fold / 8;
+    if (gm.fold >= 32 && gm.fold % 16 == 0 && nch <= 128) {
+        const int rpb = 256 / nch;
+        long nb = (gm.M + rpb - 1) / rpb; if (nb > 16384) nb = 16384;
+        hipLaunchKernelGGL(gsm_bwd_gate_rows_kernel, dim3((int)nb), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate, dpre,
+                           gm, rpb, make_fastdiv(nch));
+        STES_LAUNCH_CHECK();
+        return STES_OK;
+    }
     long blocks = (gm.M * 2 + 255) / 256; if (blocks > 8192) blocks = 8192;
     if (gm.fold == 8) hipLaunchKernelGGL(gsm_bwd_gate_kernel<4>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate, dpre, gm);
     else hipLaunchKernelGGL(gsm_bwd_gate_kernel<8>, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)dG, (const bf16*)Xc, gate, dpre, gm);
