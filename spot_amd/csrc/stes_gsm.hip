@@ -539,6 +539,61 @@ __global__ __launch_bounds__(256) void gsm_dxbn_kernel(const float* __restrict__
     }
 }
 
+// The same for the narrow slices (fold 8 and 16, the high-resolution stages): thread = position doing BOTH groups, so that a
+// position's row of `fold` channels is loaded and stored whole (16 or 32 bytes per lane, contiguous across the wave) and
+// the gate gradient of both groups arrives as one 8-byte load.  workgroup = (row tile, frame, clip).
+template <int FOLD>
+__global__ __launch_bounds__(256) void gsm_dxbn_rows_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ w3d, bf16* __restrict__ dxbn, Geom gm, int TH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HALF = FOLD / 2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2* tile = (f32x2*)smem;                            // [3][TH+2][W+2] (group 0, group 1)
+    const int b = blockIdx.z, t = blockIdx.y, h0 = blockIdx.x * TH;
+    const int W = gm.W, H = gm.H, W2 = W + 2, rows = TH + 2;
+    const long plane = (long)H * W;
+    const int items = 3 * rows * W2;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int wp = i % W2; int r = i / W2;
+        const int hr = r % rows, kt = r / rows;
+        const int tt = t + kt - 1, hh = h0 + hr - 1, ww = wp - 1;
+        f32x2 v = {0.f, 0.f};
+        if (tt >= 0 && tt < gm.T && hh >= 0 && hh < H && ww >= 0 && ww < W)
+            v = *reinterpret_cast<const f32x2*>(dpre + (((long)(b * gm.T + tt)) * plane + (long)hh * W + ww) * 2);
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int nout = TH * W;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int hr = o / W, ww = o - hr * W;
+        const int hh = h0 + hr;
+        if (hh >= H) continue;
+        f32x2 dp[27];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    dp[(kt * 3 + kh) * 3 + kw] = tile[((2 - kt) * rows + hr + 2 - kh) * W2 + ww + 2 - kw];
+        const long m = ((long)(b * gm.T + t)) * plane + (long)hh * W + ww;
+        float x[FOLD], out[FOLD];
+#pragma unroll
+        for (int c = 0; c < FOLD; c += 8) load8b(Xc + m * FOLD + c, *reinterpret_cast<float(*)[8]>(&x[c]));
+#pragma unroll
+        for (int c = 0; c < FOLD; ++c) {
+            const float* wc = w3d + c * 27;                // [2][HALF][27] flat = [FOLD][27]: wave-uniform scalar loads
+            float a = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 27; ++tp) a += wc[tp] * (c < HALF ? dp[tp][0] : dp[tp][1]);
+            out[c] = (x[c] * scale[c] + shift[c] > 0.f) ? a : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < FOLD; c += 8) store8b(dxbn + m * FOLD + c, *reinterpret_cast<float(*)[8]>(&out[c]));
+    }
+}
+
 // ------------------------------------------------------------------ backward: input gradient (elementwise)
 // dXf[m,c] = dG[m,c] + gate[m,g]*(dG[m -+ plane, c] - dG[m,c]) + alpha[c]*dxbn[m,c] + beta[c]*x[m,c] + delta[c]
 template <int V>
@@ -781,6 +836,17 @@ extern "C" int stes_gsm_dxbn(const float* dpre, const uint16_t* Xc, const float*
     int rc = check_geom(g); if (rc) return rc;
     STES_CHECK(dpre && Xc && scale && shift && w3d && dxbn, STES_ERR_ARG, "stes_gsm_dxbn: null pointer");
     const Geom gm = to_geom(g);
+    if (gm.fold == 8 || gm.fold == 16) {
+        const int th = tile_rows(gm, 8);
+        const size_t lds2 = (size_t)3 * (th + 2) * (gm.W + 2) * 8;
+        const dim3 grid2(stes_div_up(gm.H, th), gm.T, gm.B);
+        if (gm.fold == 8)
+            hipLaunchKernelGGL(gsm_dxbn_rows_kernel<8>, grid2, dim3(256), lds2, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d, (bf16*)dxbn, gm, th);
+        else
+            hipLaunchKernelGGL(gsm_dxbn_rows_kernel<16>, grid2, dim3(256), lds2, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d, (bf16*)dxbn, gm, th);
+        STES_LAUNCH_CHECK();
+        return STES_OK;
+    }
     const int th = tile_rows(gm, 4);
     const size_t lds = (size_t)3 * (th + 2) * (gm.W + 2) * 4;
     const dim3 grid(stes_div_up(gm.H, th), gm.T, gm.B * 2);
