@@ -489,7 +489,7 @@ __device__ __forceinline__ int gsm_dest(int c, int fold) {
 }
 
 template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
-__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, RowDivs dv) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv) {
     constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
     constexpr int FI = T / 32;               // 16-wide fragments per wave per operand
     constexpr int CH = T / 8;                // 16-byte chunks per tile row
@@ -501,16 +501,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave >> 1, w2 = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n1_0 = blockIdx.y * T, n2_0 = blockIdx.z * T;
-    const long m_begin = (long)blockIdx.x * m_chunk;
+    // workgroup -> (tile, row chunk): the t1*t2 tiles of a row chunk are consecutive workgroups of ONE XCD (workgroups go
+    // round-robin over the 8 XCDs), so a chunk of P and Q comes from HBM once and its other readers hit that XCD's L2
+    // (with few row chunks that would leave XCDs idle: then m_blocks < 0 selects chunk-major order over all XCDs)
+    int tile, mblk;
+    if (m_blocks > 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = idx % (t1 * t2);
+        mblk = (idx / (t1 * t2)) * 8 + xcd;
+    } else {
+        m_blocks = -m_blocks;
+        mblk = blockIdx.x % m_blocks;
+        tile = blockIdx.x / m_blocks;
+    }
+    const int by = tile % t1, bz = tile / t1;
+    const int n1_0 = by * T, n2_0 = bz * T;
+    const long m_begin = (long)mblk * m_chunk;
     const long m_end = (m_begin + m_chunk < p.M) ? m_begin + m_chunk : p.M;
-    if (m_begin >= m_end) return;
+    if (mblk >= m_blocks || m_begin >= m_end) return;
 
     const bf16* __restrict__ P = (const bf16*)p.P;
     const bf16* __restrict__ Q = (const bf16*)p.Q;
     const bf16* __restrict__ Q0 = (const bf16*)p.Q0;
     const bool has_affine = p.q_scale != nullptr, has_gate = p.q_gate != nullptr;
-    const bool do_bias = p.dbias != nullptr && blockIdx.z == 0;
+    const bool do_bias = p.dbias != nullptr && bz == 0;
     if (do_bias && tid < T) bias_acc[tid] = 0.f;
 
     const int lc = tid % CH, lr = tid / CH;          // loader: chunk, row (row step 256/CH)
@@ -751,8 +765,12 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
     dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
     dv.gate = make_fastdiv(a->q_gate ? a->gate_group : 1);
-    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, dv);
-    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(mb, t1, t2), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, dv);
+    // several tiles re-reading each row chunk and enough chunks to balance 8 XCDs: tiles of a chunk share an XCD
+    const bool xcd_map = t1 * t2 >= 4 && mb >= 48;   // (measured: with 3 tiles or fewer the chunk-major order is faster)
+    const int grid = xcd_map ? (mb + 7) / 8 * 8 * t1 * t2 : mb * t1 * t2;
+    const int mb_arg = xcd_map ? mb : -mb;
+    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
