@@ -269,10 +269,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
 #ifndef STES_STREAM_DEPTH
 #define STES_STREAM_DEPTH 4
 #endif
-template <int NI, int WAVES, bool GATE>   // NB = 16*NI columns per workgroup
+// PRO selects the operand prologue: 0 none or BatchNorm+ReLU (a_scale/a_shift), 1 the same plus the squeeze-excite gate,
+// 2 BatchNorm backward: A is the gradient at a BatchNorm's output, a_raw the raw tensor under that BatchNorm, and the operand
+// is bf16(alpha*A + beta*a_raw + delta) -- what stes_bn_bwd_apply would have written; it is written here too (a_out, by the
+// workgroups of column slice 0) for the weight-gradient kernel, which saves that kernel's pass and one read of its result.
+template <int NI, int WAVES, int PRO>   // NB = 16*NI columns per workgroup
 __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
                                                                  RowDivs dv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool GATE = PRO == 1, BNB = PRO == 2;
     constexpr int NB = NI * 16, D = STES_STREAM_DEPTH;
     constexpr int CPR = NB / 8;                 // 16-byte chunks per output row
     constexpr int RPP = 64 / CPR;               // output rows per store pass of a wave
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     float* sc_s = reinterpret_cast<float*>(smem + NB * RS + WAVES * 16 * SRS);
     float* sh_s = sc_s + K;
     float* red = sh_s + K;                      // [2][NB]
+    float* de_s = red + 2 * NB;                 // [K], BNB only (sc_s = alpha, sh_s = beta, de_s = delta)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     const int n0 = slice * NB;
     const bf16* __restrict__ A = (const bf16*)p.A;
     const bf16* __restrict__ A0 = (const bf16*)p.A0;
-    const bool has_affine = p.a_scale != nullptr;
+    const bf16* __restrict__ R = (const bf16*)p.a_raw;
+    const bool has_affine = !BNB && p.a_scale != nullptr;
     const bool stats = p.col_sum != nullptr;
     const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
 
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
             *reinterpret_cast<bf16x8*>(wl + r * RS + kc * 16) = v;
         }
         if (has_affine) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.a_scale[k]; sh_s[k] = p.a_shift[k]; }
+        if (BNB) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.bn_alpha[k]; sh_s[k] = p.bn_beta[k]; de_s[k] = p.bn_delta[k]; }
         for (int k = tid; k < 2 * NB; k += WAVES * 64) red[k] = 0.f;
     }
     __syncthreads();
@@ -316,12 +324,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     const long tstride = (long)m_slots * WAVES;
     long f_tile = (long)slot * WAVES + wave, c_tile = f_tile;
     int f_ks = 0, c_ks = 0;
-    const bf16* f_a[2]; const bf16* f_a0[2];
+    const bf16* f_a[2]; const bf16* f_a0[2]; const bf16* f_r[2];
     auto f_rows = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const long m = f_tile * 32 + j * 16 + fr;
-            f_a[j] = nullptr; f_a0[j] = nullptr;
+            f_a[j] = nullptr; f_a0[j] = nullptr; f_r[j] = nullptr;
             if (f_tile < row_tiles && m < M) {
                 long src = m;
                 if (p.map_stride > 1) {
@@ -332,6 +340,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
                 }
                 f_a[j] = A + src * p.lda;
                 if (A0) f_a0[j] = A0 + src * p.lda0;
+                if (BNB) f_r[j] = R + src * p.lda;
             }
         }
     };
@@ -347,12 +356,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
         }
     };
     bf16x8 ring[D][2];
+    bf16x8 ring_r[BNB ? D : 1][2];
     auto fetch = [&](int d) {
         const int k = f_ks * 32 + fq * 8;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (f_a[j] != nullptr) ring[d][j] = *reinterpret_cast<const bf16x8*>((k < p.k0 ? f_a0[j] : f_a[j]) + k);
             else ring[d][j] = zero8();
+            if (BNB) ring_r[d][j] = f_r[j] != nullptr ? *reinterpret_cast<const bf16x8*>(f_r[j] + k) : zero8();
         }
         if (++f_ks == nk) { f_ks = 0; f_tile += tstride; f_rows(); }
     };
@@ -379,6 +390,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
             // ---- prologue on the two A fragments of this k-step
             bf16x8 fb[2] = {ring[d][0], ring[d][1]};
             const int k = c_ks * 32 + fq * 8;
+            if (BNB) {
+                float al[8], be[8], de[8];
+                load8f(sc_s + k, al); load8f(sh_s + k, be); load8f(de_s + k, de);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float f[8], r[8];
+                    unpack8(fb[j], f);
+                    unpack8(ring_r[d][j], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = al[e] * f[e] + be[e] * r[e] + de[e];
+                    fb[j] = pack8(f);
+                    const long m = c_tile * 32 + j * 16 + fr;
+                    if (p.a_out && slice == 0 && m < M) *reinterpret_cast<bf16x8*>(p.a_out + m * p.lda_out + k) = fb[j];
+                }
+            }
             if (has_affine || GATE) {
                 float s[8], b[8];
                 if (has_affine) { load8f(sc_s + k, s); load8f(sh_s + k, b); }
@@ -476,7 +502,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
 }
 
 // ------------------------------------------------------------------ wgrad
-constexpr int WK = 32;                       // rows (reduction) per step
 __device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
 }
@@ -490,13 +515,17 @@ __device__ __forceinline__ int gsm_dest(int c, int fold) {
 
 template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
 __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv) {
+    constexpr int WK = T == 128 ? 64 : 32;   // rows (reduction) per step and barrier: the large tile amortises the barrier
+                                             // over two MFMA k-blocks; for the HBM-bound small tile that only costs residency
     constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
     constexpr int FI = T / 32;               // 16-wide fragments per wave per operand
     constexpr int CH = T / 8;                // 16-byte chunks per tile row
     constexpr int LOADS = (WK * CH) / 256;   // chunk loads per thread per operand (2 or 1)
-    __shared__ __attribute__((aligned(16))) bf16 Ps[2][WK * LDT];
-    __shared__ __attribute__((aligned(16))) bf16 Qs[2][WK * LDT];
-    __shared__ float bias_acc[T];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];      // wgrad_lds_bytes<T>()
+    typedef bf16 TileBuf[WK * LDT];
+    TileBuf* Ps = reinterpret_cast<TileBuf*>(wg_smem);                            // [2]
+    TileBuf* Qs = Ps + 2;                                                        // [2]
+    float* bias_acc = reinterpret_cast<float*>(Qs + 2);                          // [T]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave >> 1, w2 = wave & 1;
@@ -541,6 +570,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
+    float qsc[8], qsh[8];      // this thread's 8 columns of the prologue's scale / shift
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qsc[i] = (has_affine && c2_ok) ? p.q_scale[c2 + i] : 1.f; qsh[i] = (has_affine && c2_ok) ? p.q_shift[c2 + i] : 0.f; }
     bf16x8 rp[LOADS], rq[LOADS];
     long qm[LOADS];   // logical row of each staged q chunk (for the gate lookup)
     auto gload = [&](long mb) {
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
                 if (has_affine) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        f[i] = f[i] * p.q_scale[c2 + i] + p.q_shift[c2 + i];
+                        f[i] = f[i] * qsc[i] + qsh[i];
                         if (p.q_relu) f[i] = fmaxf(f[i], 0.f);
                     }
                 }
@@ -603,33 +635,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     for (long mb = m_begin; mb < m_end; mb += WK) {
         const bool more = mb + WK < m_end;
         if (more) gload(mb + WK);
-        bf16x8 fa[FI], fb[FI];
-        // transposed fragment reads: lane supplies row 8*fq + (fr>>2) (+4), columns 4*(fr&3)..+3
+        // transposed fragment reads: lane supplies row 8*fq + (fr>>2) (+4) of a 32-row k-block, columns 4*(fr&3)..+3
         const int r_lo = rho(8 * fq + (fr >> 2)), r_hi = rho(8 * fq + (fr >> 2) + 4);
         const int cc = 4 * (fr & 3);
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const int col = w1 * (T / 2) + i * 16 + cc;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (bf16x4 __attribute__((address_space(3)))*)(&Ps[buf][r_lo * LDT + col]));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (bf16x4 __attribute__((address_space(3)))*)(&Ps[buf][r_hi * LDT + col]));
-            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int kk = 0; kk < WK / 32; ++kk) {
+            bf16x8 fa[FI], fb[FI];
+            const bf16* ps = &Ps[buf][kk * 32 * LDT];
+            const bf16* qs = &Qs[buf][kk * 32 * LDT];
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int col = w1 * (T / 2) + i * 16 + cc;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ps + r_lo * LDT + col));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ps + r_hi * LDT + col));
+                fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < FI; ++j) {
+                const int col = w2 * (T / 2) + j * 16 + cc;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(qs + r_lo * LDT + col));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(qs + r_hi * LDT + col));
+                fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < FI; ++j) {
-            const int col = w2 * (T / 2) + j * 16 + cc;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (bf16x4 __attribute__((address_space(3)))*)(&Qs[buf][r_lo * LDT + col]));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (bf16x4 __attribute__((address_space(3)))*)(&Qs[buf][r_hi * LDT + col]));
-            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < FI; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -656,21 +689,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     }
 }
 
+template <int T>
+static size_t wgrad_lds_bytes() {
+    static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   160 * 1024) == hipSuccess;
+    (void)raised;
+    return (size_t)4 * (T == 128 ? 64 : 32) * (T + 16) * sizeof(bf16) + T * sizeof(float);
+}
+
 // Workgroups of one streaming-GEMM instantiation resident per CU at a given dynamic LDS size (cached: queried once per size).
-template <int NI, int WAVES, bool GATE>
+template <int NI, int WAVES, int PRO>
 static int stream_residency(size_t lds) {
     static bool attr_done = false;
     static size_t seen[8];
     static int val[8];
     static int n_seen = 0;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, GATE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, PRO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     for (int i = 0; i < n_seen; ++i) if (seen[i] == lds) return val[i];
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_kernel<NI, WAVES, GATE>, WAVES * 64, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_kernel<NI, WAVES, PRO>, WAVES * 64, lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
     if (n_seen < 8) { seen[n_seen] = lds; val[n_seen] = per_cu; ++n_seen; }
     return per_cu;
@@ -690,6 +731,11 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     STES_CHECK(!(a->col_sum && a->c_f32), STES_ERR_ARG, "stes_gemm: stats need bf16 output");
     STES_CHECK(a->n_split == 0 || (a->C0 && !a->c_f32 && a->n_split % 4 == 0 && a->ldc0 % 4 == 0 && a->ldc0 >= a->n_split), STES_ERR_ARG, "stes_gemm: split output");
     STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_gemm: more than 2^31 rows");
+    const bool bnb = a->a_raw != nullptr;
+    STES_CHECK(!bnb || (a->bn_alpha && a->bn_beta && a->bn_delta && !a->a_scale && !a->a_gate && a->k0 == 0 && a->map_stride <= 1 &&
+                        (!a->a_out || (a->lda_out % 8 == 0 && a->lda_out >= a->K))),
+               STES_ERR_ARG, "stes_gemm: the BatchNorm-backward prologue needs alpha/beta/delta and excludes the other prologues");
+    STES_CHECK(bnb || !a->a_out, STES_ERR_ARG, "stes_gemm: a_out without a_raw");
     RowDivs dv;
     dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
     dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
@@ -704,7 +750,8 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
                           (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0));
         if (fits) {
             const int ni = nb / 16, waves = nb >= 128 ? 8 : 4;
-            const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) + (size_t)(2 * a->K + 2 * nb) * sizeof(float);
+            const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) +
+                               (size_t)((bnb ? 3 : 2) * a->K + 2 * nb) * sizeof(float);
             const int n_slices = a->N / nb;
             const int row_tiles = stes_div_up(a->M, 32);
             int per_cu = 1;
@@ -718,16 +765,18 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
         hipLaunchKernelGGL((gemm_stream_kernel<NI_, W_, G_>), dim3(grid), dim3(W_ * 64), lds, (hipStream_t)stream, *a, row_tiles,   \
                            n_slices, m_slots, dv);                                                                                 \
     } while (0)
-            const bool g = a->a_gate != nullptr;
-            if (ni == 2) STREAM_CASE(2, 4, false);
-            else if (ni == 4) { if (g) STREAM_CASE(4, 4, true); else STREAM_CASE(4, 4, false); }
-            else if (ni == 8) { if (g) STREAM_CASE(8, 8, true); else STREAM_CASE(8, 8, false); }
-            else { if (g) STREAM_CASE(10, 8, true); else STREAM_CASE(10, 8, false); }
+            const int pro = bnb ? 2 : (a->a_gate != nullptr ? 1 : 0);
+            if (ni == 2) { if (pro == 2) STREAM_CASE(2, 4, 2); else STREAM_CASE(2, 4, 0); }
+            else if (ni == 4) { if (pro == 2) STREAM_CASE(4, 4, 2); else if (pro == 1) STREAM_CASE(4, 4, 1); else STREAM_CASE(4, 4, 0); }
+            else if (ni == 8) { if (pro == 2) STREAM_CASE(8, 8, 2); else if (pro == 1) STREAM_CASE(8, 8, 1); else STREAM_CASE(8, 8, 0); }
+            else { if (pro == 2) STREAM_CASE(10, 8, 2); else if (pro == 1) STREAM_CASE(10, 8, 1); else STREAM_CASE(10, 8, 0); }
 #undef STREAM_CASE
             STES_LAUNCH_CHECK();
             return STES_OK;
         }
     }
+    STES_CHECK(!bnb, STES_ERR_UNSUPPORTED, "stes_gemm: the BatchNorm-backward prologue exists for the streaming shapes only "
+                                           "(N in {32,64,128,160,320}, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
     const int m_tiles = stes_div_up(a->M, BM);
     const bool wide = a->N > 64;
     const int bn = wide ? 128 : 64;
@@ -758,7 +807,7 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     if (want < 1) want = 1;
     long chunk = (a->M + want - 1) / want;
     if (chunk < 256) chunk = 256;
-    chunk = (chunk + WK - 1) / WK * WK;
+    chunk = (chunk + 63) / 64 * 64;
     const int mb = stes_div_up(a->M, chunk);
     STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_wgrad: more than 2^31 rows");
     RowDivs dv;
@@ -769,8 +818,8 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     const bool xcd_map = t1 * t2 >= 4 && mb >= 48;   // (measured: with 3 tiles or fewer the chunk-major order is faster)
     const int grid = xcd_map ? (mb + 7) / 8 * 8 * t1 * t2 : mb * t1 * t2;
     const int mb_arg = xcd_map ? mb : -mb;
-    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
-    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), wgrad_lds_bytes<128>(), (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), wgrad_lds_bytes<64>(), (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

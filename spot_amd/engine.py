@@ -224,13 +224,17 @@ class Block:
             sums = [bn3.s_dy, bn3.s_dyr] + ([self.bnd.s_dyr] if self.down else [])
             lib.bn_bwd_reduce(dZ, self.c3, Mo, cout, sums, raw2=self.sc if self.down else None)
         bn3.bwd_finalize(Mo)
-        dc3 = sc("dc3", Mo * cout)
-        lib.bn_bwd_apply(dZ, self.c3, Mo, cout, bn3.coef, dc3)
-        # --- conv3 (1x1): weight and input gradients
+        # Where the input-gradient GEMM runs on the streaming kernel (stages 1-3) it applies the BatchNorm backward itself, in
+        # its operand prologue, and writes the result (dc3) on the way for the weight gradient; elsewhere a separate pass does.
+        dc3, dA3 = sc("dc3", Mo * cout), sc("dA3", Mo * cmid)
+        if lib.gemm_streams(Mo, cmid, cout):
+            lib.gemm(dZ, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np, bn_bwd=(self.c3, bn3.coef, dc3))
+        else:
+            lib.bn_bwd_apply(dZ, self.c3, Mo, cout, bn3.coef, dc3)
+            lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
+        # --- conv3 (1x1) weight gradient
         side(lambda: lib.wgrad(dc3, self.c2, g(self.l3.w), Mo, cout, cmid, scale=bn2.scale, shift=bn2.shift, relu=True,
                                gate=self.segate, gate_group=HWo))
-        dA3 = sc("dA3", Mo * cmid)
-        lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
         # --- squeeze-excite backward
         dgate = sc("se.dgate", self.N * cmid, F32)
         S4 = sc("se.S4", 4 * self.N * cmid, F32)
@@ -256,13 +260,17 @@ class Block:
         lib.call("stes_conv3x3g_dgrad", p(dc2), p(self.wp2_d), p(dA2), p(self.c1), p(bn1.scale), p(bn1.shift), p(bn1.s_dy), p(bn1.s_dyr), *geo)
         bn1.bwd_finalize(Mi)
         dc1 = sc("dc1", Mi * cmid)
-        lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1)
-        # --- conv1 (1x1)
+        # --- conv1 (1x1): input gradient (with the BatchNorm backward in its prologue where it streams), weight gradient
         q0, k0 = (self.G, self.fold) if self.kind == "gsm" else (None, 0)
-        side(lambda: lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold))
         dY1 = sc("dY1", Mi * cin)
         dG = sc("gsm.dG", Mi * self.fold) if self.kind == "gsm" else None
-        lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, ldw=self.l1.Np, C0=dG, ldc0=self.fold, n_split=self.fold)
+        kw1 = dict(ldw=self.l1.Np, C0=dG, ldc0=self.fold, n_split=self.fold)
+        if lib.gemm_streams(Mi, cin, cmid):
+            lib.gemm(dA2, self.l1.wT_bf, dY1, Mi, cin, cmid, bn_bwd=(self.c1, bn1.coef, dc1), **kw1)
+        else:
+            lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1)
+            lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, **kw1)
+        side(lambda: lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold))
         dXf = None
         if self.kind == "gsm":
             gs, bng, geom, Xc, fold = self.gsm, self.bng, self.geom, self.Xc, self.fold
@@ -284,12 +292,14 @@ class Block:
         if self.down:
             bnd = self.bnd
             bnd.bwd_finalize(Mo, s_dy=bn3.s_dy)
-            dsc = sc("dsc", Mo * cout)
-            lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
+            dsc, Dsc = sc("dsc", Mo * cout), sc("Dsc", Mo * cin)
+            if lib.gemm_streams(Mo, cin, cout):
+                lib.gemm(dZ, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np, bn_bwd=(self.sc, bnd.coef, dsc))
+            else:
+                lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
+                lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
             rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
             side(lambda: lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap))
-            Dsc = sc("Dsc", Mo * cin)
-            lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
             resid, ms = Dsc, self.stride
         else:
             resid, ms = dZ, 1

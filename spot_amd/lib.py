@@ -37,7 +37,8 @@ GemmArgs = _struct("GemmArgs", [
     ("col_sum", _P), ("col_sumsq", _P),
     ("relu_mask", _P), ("ldmask", _I64),
     ("C0", _P), ("ldc0", _I64), ("n_split", _I32),
-    ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32)])
+    ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32),
+    ("a_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("a_out", _P), ("lda_out", _I64)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -178,7 +179,15 @@ def _gemm_work(a, out_bytes):
         byt += (m // max(a.gate_group, 1)) * k * 4
     if a.relu_mask:
         byt += m * n * 2
+    if a.a_raw:
+        byt += m * k * 2 * (2 if a.a_out else 1)
     return byt, 2 * m * n * k
+
+
+def gemm_streams(M, N, K):
+    """True when stes_gemm runs an [M,K] x [N,K]^T bf16 product on its streaming kernel (the rule in stes_gemm.hip), the
+    only one with the BatchNorm-backward prologue."""
+    return N in (32, 64, 128, 160, 320) and K % 32 == 0 and K <= 320 and M >= 8192
 
 
 def _gemm_kernel(a):
@@ -187,15 +196,16 @@ def _gemm_kernel(a):
                  and (not a.a_gate or a.N >= 64))
     if stream_ok:
         nb = 160 if a.N == 320 else a.N
-        return "gemm_stream_kernel<%d, %d, %s>" % (nb // 16, 8 if nb >= 128 else 4, "true" if a.a_gate else "false")
+        return "gemm_stream_kernel<%d, %d, %d>" % (nb // 16, 8 if nb >= 128 else 4, 2 if a.a_raw else (1 if a.a_gate else 0))
     return "gemm_kernel<128>" if a.N > 64 else "gemm_kernel<64>"
 
 
 # ---------------------------------------------------------------- struct-argument entry points
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
-         bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0):
-    """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h."""
+         bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0,
+         bn_bwd=None):
+    """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta), a_out | None)."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
     a.A0, a.lda0, a.k0 = ptr(A0), lda0, k0
@@ -211,6 +221,10 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     a.relu_mask, a.ldmask = ptr(relu_mask), ldmask
     a.C0, a.ldc0, a.n_split = ptr(C0), ldc0, n_split
     a.M, a.N, a.K, a.out_scale = M, N, K, out_scale
+    if bn_bwd is not None:
+        raw, coef, a_out = bn_bwd
+        a.a_raw, a.bn_alpha, a.bn_beta, a.bn_delta = ptr(raw), ptr(coef[0]), ptr(coef[1]), ptr(coef[2])
+        a.a_out, a.lda_out = ptr(a_out), K
     if TIMING is not None:
         byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
         _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))

@@ -135,3 +135,39 @@ def test_wgrad(M, N1, N2):
     torch.cuda.synchronize()
     torch.testing.assert_close(dW.cpu(), ref, rtol=2e-3, atol=2e-3 * M ** 0.5)
     torch.testing.assert_close(db.cpu(), P[:, :N1].float().sum(0), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,K", [(32, 64), (64, 128), (128, 128), (128, 320), (320, 320)])
+def test_gemm_bn_backward_prologue_equals_apply_then_gemm(N, K):
+    """The streaming GEMM's BatchNorm-backward prologue (operand = alpha*dY + beta*raw + delta, rounded to bf16, also stored
+    for the weight gradient) against stes_bn_bwd_apply followed by the plain GEMM: same bits in both outputs, with the split
+    output the gated-shift blocks use; shapes outside the streaming kernel are refused."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(N + 3 * K)
+    M = 3 * 53 * 52
+    D, raw, W = _bf(M, K, g=g), _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5)
+    coef = [dev(torch.randn(K, generator=g) * s) for s in (1.0, 0.3, 0.1)]
+    dD, dR, dW_ = dev(D), dev(raw), dev(W)
+    dc_ref = torch.full((M, K), 3.0, dtype=torch.bfloat16, device="cuda")
+    lib.bn_bwd_apply(dD, dR, M, K, coef, dc_ref)
+    split = 16 if N >= 64 else 0
+    mk = lambda: (torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda"),
+                  torch.full((M, 16), 5.0, dtype=torch.bfloat16, device="cuda") if split else None)
+    C_ref, C0_ref = mk()
+    lib.gemm(dc_ref, dW_, C_ref, M, N, K, C0=C0_ref, ldc0=16, n_split=split)
+    C_got, C0_got = mk()
+    dc_got = torch.full((M, K), 4.0, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(dD, dW_, C_got, M, N, K, C0=C0_got, ldc0=16, n_split=split, bn_bwd=(dR, coef, dc_got))
+    torch.cuda.synchronize()
+    assert torch.equal(dc_got.view(torch.int16), dc_ref.view(torch.int16))
+    assert torch.equal(C_got[:, split:].view(torch.int16), C_ref[:, split:].view(torch.int16))
+    if split:
+        assert torch.equal(C0_got.view(torch.int16), C0_ref.view(torch.int16))
+    # without the side output
+    C2, _ = mk()
+    lib.gemm(dD, dW_, C2, M, N, K, bn_bwd=(dR, coef, None))
+    torch.cuda.synchronize()
+    assert torch.equal(C2[:, split:].view(torch.int16), C_ref[:, split:].view(torch.int16))
+    assert lib.gemm_streams(M, N, K)
+    with pytest.raises(lib.StesError):
+        lib.gemm(dD, dW_, C2, 4096, N, K, bn_bwd=(dR, coef, None))          # too few rows for the streaming kernel
