@@ -251,6 +251,15 @@ int stes_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
  * perm_fold source columns through the gated-shift channel interleave (see the temporal shift section). */
 int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, int perm_fold,
                    void* stream);
+/* The same for a whole table of copies in ONE launch.  `table` is DEVICE memory holding n entries; entry e owns the
+ * workgroups [block0, block0 + ceil(dst_rows*ld / 256)) and the entries are sorted by block0 (entry 0 has block0 = 0);
+ * total_blocks is the sum.  Field meaning as in stes_cast_bf16.                                                        */
+typedef struct {
+    const float* src; uint16_t* dst;
+    int32_t rows, cols, ld, dst_rows, transpose, perm_fold;
+    int32_t block0, reserved;
+} stes_cast_desc;
+int stes_cast_bf16_multi(const stes_cast_desc* table, int n, int total_blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -294,6 +294,27 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict
     }
 }
 
+// All weight copies of a step in one launch: workgroup -> (table entry, 256-element chunk) by binary search over the
+// entries' first workgroup.  ~140 launches of a few microseconds each otherwise sit at the head of every training step.
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const stes_cast_desc* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const stes_cast_desc d = table[lo];
+    const long i = (long)(blockIdx.x - d.block0) * 256 + threadIdx.x;
+    if (i >= (long)d.dst_rows * d.ld) return;
+    const int dr = (int)(i / d.ld), dc = (int)(i - (long)dr * d.ld);
+    float v = 0.f;
+    if (!d.transpose) {
+        if (dr < d.rows && dc < d.cols) v = d.src[(long)dr * d.cols + (dc < d.perm_fold ? gsm_dest(dc, d.perm_fold) : dc)];
+    } else {
+        if (dc < d.rows && dr < d.cols) v = d.src[(long)dc * d.cols + (dr < d.perm_fold ? gsm_dest(dr, d.perm_fold) : dr)];
+    }
+    reinterpret_cast<bf16*>(d.dst)[i] = (bf16)v;
+}
+
 }  // namespace
 
 #define S(s) ((hipStream_t)(s))
@@ -374,6 +395,13 @@ extern "C" int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int col
     STES_CHECK(transpose ? (ld >= rows && dst_rows >= cols) : (ld >= cols && dst_rows >= rows), STES_ERR_ARG, "stes_cast_bf16: destination too small");
     long blocks = ((long)dst_rows * ld + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, S(stream), src, (bf16*)dst, rows, cols, ld, dst_rows, transpose, perm_fold);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_cast_bf16_multi(const stes_cast_desc* table, int n, int total_blocks, void* stream) {
+    STES_CHECK(table && n > 0 && total_blocks > 0, STES_ERR_ARG, "stes_cast_bf16_multi: bad argument");
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(total_blocks), dim3(256), 0, S(stream), table, n);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

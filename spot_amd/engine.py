@@ -353,6 +353,7 @@ class Engine:
         self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
         self._stats_used = 0
         self._scratch, self._acts, self._pp = {}, {}, {}
+        self._cast_table = None
         self._flatten()
         feats = impl._features
         self.in_chans = feats.stem.conv.in_channels
@@ -528,8 +529,18 @@ class Engine:
     def refresh_weights(self):
         self.check_views()
         p = lib.ptr
-        for src, dst, rows, cols, ld, dst_rows, tr, pf in self.casts:
-            lib.call("stes_cast_bf16", p(src), p(dst), rows, cols, ld, dst_rows, tr, pf)
+        if self._cast_table is None:
+            # one launch for every bf16 weight copy: the descriptor table lives on the device (sources are views into the
+            # flat parameter buffer and destinations are fixed, so it is built once)
+            arr = (lib.CastDesc * len(self.casts))()
+            blk = 0
+            for d, (src, dst, rows, cols, ld, dst_rows, tr, pf) in zip(arr, self.casts):
+                d.src, d.dst, d.rows, d.cols, d.ld, d.dst_rows, d.transpose, d.perm_fold, d.block0 = (
+                    src.data_ptr(), dst.data_ptr(), rows, cols, ld, dst_rows, tr, pf, blk)
+                blk += (dst_rows * ld + 255) // 256
+            self._cast_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            self._cast_blocks = blk
+        lib.call("stes_cast_bf16_multi", p(self._cast_table), len(self.casts), self._cast_blocks)
         for w3d, wt, fold in self.gsm_preps:
             lib.call("stes_gsm_prep", p(w3d), p(wt), fold)
         for w, wf, wd, G, stride in self.packs:

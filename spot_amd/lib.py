@@ -55,6 +55,9 @@ BnBwdArgs = _struct("BnBwdArgs", [
     ("alpha", _P), ("beta", _P), ("delta", _P), ("out", _P),
     ("M", _I64), ("C", _I32)])
 
+CastDesc = _struct("CastDesc", [("src", _P), ("dst", _P), ("rows", _I32), ("cols", _I32), ("ld", _I32), ("dst_rows", _I32),
+                                ("transpose", _I32), ("perm_fold", _I32), ("block0", _I32), ("reserved", _I32)])
+
 GsmGeom = _struct("GsmGeom", [("B", _I32), ("T", _I32), ("H", _I32), ("W", _I32), ("fold", _I32)])
 
 GruArgs = _struct("GruArgs", [
@@ -101,6 +104,7 @@ _SIGS = {
     "stes_loss": [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _F32, _F32, _P, _P, _P, _P, _P],
     "stes_adamw": [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _F32, _P],
     "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
 EXPORTS = ["stes_version", "stes_last_error"] + list(_SIGS)
 
