@@ -157,6 +157,10 @@ _KERNEL_OF = {
     "stes_conv3x3g_dgrad": ("conv3x3g_rows_kernel / conv3x3g_dgrad2_kernel (input gradient)",
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
     "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
+    # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums...): every operand once
+    "stes_block_in_grad": (lambda a: "block_in_grad_kernel<%s>" % ("true" if a[14] is not None else "false"),
+                           lambda a: 2 * a[12] * a[13] * (3 + (a[14] is not None) + (a[15] is not None))
+                           + (2 * a[12] * a[13] // (a[5] * a[5]) if a[4] is not None else 0)),
 }
 
 
@@ -171,6 +175,8 @@ def _timed(kernel, nbytes, flops, fn):
 def call(name, *args):
     if TIMING is not None:
         kernel, fb = _KERNEL_OF.get(name, (name.replace("stes_", "") + "_kernel", None))
+        if callable(kernel):
+            kernel = kernel(args)
         _timed(kernel, fb(args) if fb else None, 0, lambda: check(getattr(lib(), name)(*args, stream()), name))
         return
     check(getattr(lib(), name)(*args, stream()), name)
