@@ -513,14 +513,18 @@ __device__ __forceinline__ int gsm_dest(int c, int fold) {
     return g * half + 2 * j + i;
 }
 
-template <int T>   // T x T output tile (T = 128 or 64), 4 waves 2x2
-__global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv) {
+// T x T output tile (T = 128 or 64) by WAVES waves arranged 2 x WAVES/2.  Eight waves on the 128 tile halve every wave's
+// accumulators and staging registers, so four waves fit a SIMD instead of two: the stage-3/4 shapes wait on memory latency.
+template <int T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 4 : 1))) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv) {
     constexpr int WK = T == 128 ? 64 : 32;   // rows (reduction) per step and barrier: the large tile amortises the barrier
                                              // over two MFMA k-blocks; for the HBM-bound small tile that only costs residency
     constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
-    constexpr int FI = T / 32;               // 16-wide fragments per wave per operand
+    constexpr int NT = WAVES * 64;
+    constexpr int FI = T / 32;               // 16-wide fragments per wave of P (N1 side)
+    constexpr int FJ = T / (8 * WAVES);      // ... of Q (N2 side)
     constexpr int CH = T / 8;                // 16-byte chunks per tile row
-    constexpr int LOADS = (WK * CH) / 256;   // chunk loads per thread per operand (2 or 1)
+    constexpr int LOADS = (WK * CH) / NT;    // chunk loads per thread per operand
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];      // wgrad_lds_bytes<T>()
     typedef bf16 TileBuf[WK * LDT];
     TileBuf* Ps = reinterpret_cast<TileBuf*>(wg_smem);                            // [2]
@@ -528,7 +532,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     float* bias_acc = reinterpret_cast<float*>(Qs + 2);                          // [T]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int w1 = wave >> 1, w2 = wave & 1;
+    constexpr int W2N = WAVES / 2;
+    const int w1 = wave / W2N, w2 = wave % W2N;
     const int fr = lane & 15, fq = lane >> 4;
     // workgroup -> (tile, row chunk): the t1*t2 tiles of a row chunk are consecutive workgroups of ONE XCD (workgroups go
     // round-robin over the 8 XCDs), so a chunk of P and Q comes from HBM once and its other readers hit that XCD's L2
@@ -556,16 +561,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     const bool do_bias = p.dbias != nullptr && bz == 0;
     if (do_bias && tid < T) bias_acc[tid] = 0.f;
 
-    const int lc = tid % CH, lr = tid / CH;          // loader: chunk, row (row step 256/CH)
-    constexpr int RSTEP = 256 / CH;
+    const int lc = tid % CH, lr = tid / CH;          // loader: chunk, row (row step NT/CH)
+    constexpr int RSTEP = NT / CH;
     const int c1 = n1_0 + lc * 8, c2 = n2_0 + lc * 8;
     const bool c1_ok = c1 < p.N1, c2_ok = c2 < p.N2;
 
-    f32x4 acc[FI][FI];
+    f32x4 acc[FI][FJ];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
         const int cc = 4 * (fr & 3);
 #pragma unroll
         for (int kk = 0; kk < WK / 32; ++kk) {
-            bf16x8 fa[FI], fb[FI];
+            bf16x8 fa[FI], fb[FJ];
             const bf16* ps = &Ps[buf][kk * 32 * LDT];
             const bf16* qs = &Qs[buf][kk * 32 * LDT];
 #pragma unroll
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
                 fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int j = 0; j < FI; ++j) {
-                const int col = w2 * (T / 2) + j * 16 + cc;
+            for (int j = 0; j < FJ; ++j) {
+                const int col = w2 * (T / W2N) + j * 16 + cc;
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(qs + r_lo * LDT + col));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(qs + r_hi * LDT + col));
                 fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
-                for (int j = 0; j < FI; ++j)
+                for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (more) lstore(buf ^ 1);
@@ -672,8 +677,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FI; ++j) {
-            const int n2 = n2_0 + w2 * (T / 2) + j * 16 + fr;
+        for (int j = 0; j < FJ; ++j) {
+            const int n2 = n2_0 + w2 * (T / W2N) + j * 16 + fr;
             const int n2d = n2 < p.perm_fold ? gsm_dest(n2, p.perm_fold) : n2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -689,9 +694,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const stes_wgrad_args p, int
     }
 }
 
-template <int T>
+template <int T, int WAVES>
 static size_t wgrad_lds_bytes() {
-    static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    160 * 1024) == hipSuccess;
     (void)raised;
     return (size_t)4 * (T == 128 ? 64 : 32) * (T + 16) * sizeof(bf16) + T * sizeof(float);
@@ -818,8 +823,13 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     const bool xcd_map = t1 * t2 >= 4 && mb >= 48;   // (measured: with 3 tiles or fewer the chunk-major order is faster)
     const int grid = xcd_map ? (mb + 7) / 8 * 8 * t1 * t2 : mb * t1 * t2;
     const int mb_arg = xcd_map ? mb : -mb;
-    if (big) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), wgrad_lds_bytes<128>(), (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
-    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), wgrad_lds_bytes<64>(), (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    if (big) {
+        const size_t lds = wgrad_lds_bytes<128, 8>();
+        hipLaunchKernelGGL((wgrad_kernel<128, 8>), dim3(grid), dim3(512), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    } else {
+        const size_t lds = wgrad_lds_bytes<64, 4>();
+        hipLaunchKernelGGL((wgrad_kernel<64, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+    }
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

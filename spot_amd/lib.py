@@ -257,7 +257,7 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
     a.perm_fold = perm_fold
     a.M, a.N1, a.N2 = M, N1, N2
     if TIMING is not None:
-        _timed("wgrad_kernel<128>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64>", 2 * M * (N1 + N2), 2 * M * N1 * N2,
+        _timed("wgrad_kernel<128, 8>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64, 4>", 2 * M * (N1 + N2), 2 * M * N1 * N2,
                lambda: check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad"))
         return
     check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")
