@@ -56,7 +56,8 @@ typedef struct {
     /* BatchNorm-backward prologue (instead of the ones above): with a_raw [M,K] (leading dimension lda; the raw tensor under
      * a BatchNorm whose output gradient is A), pro(A)[m,k] = bf16(bn_alpha[k]*A[m,k] + bn_beta[k]*a_raw[m,k] + bn_delta[k]),
      * i.e. the tensor stes_bn_bwd_apply would write, which is also stored to a_out [M,K] (lda_out) when a_out is given.
-     * Streaming shapes only (N in {32,64,128,160,320}, K % 32 == 0, K <= 320, M >= 8192, bf16 output); else UNSUPPORTED. */
+     * Streaming shapes only (N in {32,64,128,160,320} or a multiple of 128 up to 1024, K % 32 == 0, K <= 320, M >= 8192,
+     * bf16 output); else UNSUPPORTED.                                                                                    */
     const uint16_t* a_raw; const float* bn_alpha; const float* bn_beta; const float* bn_delta;
     uint16_t* a_out; int64_t lda_out;
 } stes_gemm_args;

@@ -750,6 +750,7 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
         int nb = 0;
         if (a->N == 32 || a->N == 64 || a->N == 128 || a->N == 160) nb = a->N;
         else if (a->N == 320) nb = 160;
+        else if (a->N % 128 == 0 && a->N <= 1024) nb = 128;     // wide layers with a short K (stage 4's first 1x1 conv): 128-column slices
         const bool fits = nb > 0 && a->K % 32 == 0 && a->K <= 320 && !a->c_f32 && a->M >= 8192 && a->ldc % 8 == 0 &&
                           (a->k0 == 0 || a->k0 % 8 == 0) && (a->n_split == 0 || (a->n_split % 8 == 0 && a->ldc0 % 8 == 0)) &&
                           (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0));
@@ -781,7 +782,7 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
         }
     }
     STES_CHECK(!bnb, STES_ERR_UNSUPPORTED, "stes_gemm: the BatchNorm-backward prologue exists for the streaming shapes only "
-                                           "(N in {32,64,128,160,320}, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
+                                           "(N in {32,64,128,160,320} or a multiple of 128 up to 1024, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
     const int m_tiles = stes_div_up(a->M, BM);
     const bool wide = a->N > 64;
     const int bn = wide ? 128 : 64;

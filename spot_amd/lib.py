@@ -197,15 +197,24 @@ def _gemm_work(a, out_bytes):
 def gemm_streams(M, N, K):
     """True when stes_gemm runs an [M,K] x [N,K]^T bf16 product on its streaming kernel (the rule in stes_gemm.hip), the
     only one with the BatchNorm-backward prologue."""
-    return N in (32, 64, 128, 160, 320) and K % 32 == 0 and K <= 320 and M >= 8192
+    return bool(_stream_slice(N)) and K % 32 == 0 and K <= 320 and M >= 8192
+
+
+def _stream_slice(N):
+    """Columns per workgroup of the streaming GEMM for an N-column output, 0 if it does not take N (rule in stes_gemm.hip)."""
+    if N in (32, 64, 128, 160):
+        return N
+    if N == 320:
+        return 160
+    return 128 if N % 128 == 0 and N <= 1024 else 0
 
 
 def _gemm_kernel(a):
     """Which kernel stes_gemm dispatches to (the rule in stes_gemm.hip)."""
-    stream_ok = (a.N in (32, 64, 128, 160, 320) and a.K % 32 == 0 and a.K <= 320 and not a.c_f32 and a.M >= 8192
+    stream_ok = (_stream_slice(a.N) and a.K % 32 == 0 and a.K <= 320 and not a.c_f32 and a.M >= 8192
                  and (not a.a_gate or a.N >= 64))
     if stream_ok:
-        nb = 160 if a.N == 320 else a.N
+        nb = _stream_slice(a.N)
         return "gemm_stream_kernel<%d, %d, %d>" % (nb // 16, 8 if nb >= 128 else 4, 2 if a.a_raw else (1 if a.a_gate else 0))
     return "gemm_kernel<128>" if a.N > 64 else "gemm_kernel<64>"
 

@@ -63,7 +63,7 @@ def test_gemm_prologue_stats_compact_and_rowmap():
 
 @pytest.mark.parametrize("N,K,mode", [(32, 32, "plain"), (64, 32, "rowmap"), (32, 64, "mask"), (64, 64, "gate"), (128, 64, "compact"),
                                       (128, 128, "gate"), (64, 128, "mask"), (320, 128, "plain"), (320, 320, "gate"), (128, 320, "mask"),
-                                      (160, 96, "compact")])
+                                      (160, 96, "compact"), (768, 320, "gate"), (768, 320, "mask"), (256, 64, "plain")])
 def test_gemm_streaming_path(N, K, mode):
     """Shapes that take the weights-resident streaming kernel (K <= 320, N in {32,64,128,160,320}, M >= 8192), with each
     fused option it serves: BN+ReLU(+SE gate) prologue and output statistics, compact first columns, stride-2 row map,
