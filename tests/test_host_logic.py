@@ -119,7 +119,10 @@ def test_dp_bucketed_allreduce_and_global_denominators_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000)
+    import socket
+    with socket.socket() as sk:              # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
