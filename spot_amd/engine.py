@@ -354,6 +354,8 @@ class Engine:
         self._stats_used = 0
         self._scratch, self._acts, self._pp = {}, {}, {}
         self._cast_table = None
+        self._grad_views = None
+        self._grad_of = {}
         self._flatten()
         feats = impl._features
         self.in_chans = feats.stem.conv.in_channels
@@ -479,8 +481,11 @@ class Engine:
                 raise lib.StesError("model parameters were re-allocated after the engine was built (call .to(device) before the first forward)")
 
     def grad(self, param):
-        o, n, shape = self._goff[id(param)]
-        return self.flat_grad[o:o + n].view(shape)
+        v = self._grad_of.get(id(param))
+        if v is None:
+            o, n, shape = self._goff[id(param)]
+            v = self._grad_of[id(param)] = self.flat_grad[o:o + n].view(shape)
+        return v
 
     def pair_view(self, params):
         o0, n0, s0 = self._goff[id(params[0])]
@@ -495,9 +500,14 @@ class Engine:
         """Expose the flat gradient buffer as .grad of every parameter (torch optimizers then work unchanged)."""
         if zero:
             self.flat_grad.zero_()
-        for _, p_ in self._params:
-            o, n, shape = self._goff[id(p_)]
-            p_.grad = self.flat_grad[o:o + n].view(shape)
+        if self._grad_views is None:          # the views are made once: ~300 tensor constructions per step would stall the launch queue
+            self._grad_views = []
+            for _, p_ in self._params:
+                o, n, shape = self._goff[id(p_)]
+                self._grad_views.append(self.flat_grad[o:o + n].view(shape))
+        for (_, p_), v in zip(self._params, self._grad_views):
+            if p_.grad is not v:
+                p_.grad = v
 
     # ------------------------------------------------------------------ heads
     def _build_heads(self):
