@@ -96,7 +96,9 @@ def measure_dominant_kernel(trainer, batch, steps=3):
            "step_kernel_ms": 1e3 * total / steps,
            "step_algorithmic_gb": sum(g[2] for g in groups.values() if g[4]) / steps / 1e9,
            "step_ms_with_known_bytes": 1e3 * sum(g[0] for g in groups.values() if g[4]) / steps,
-           "by_kernel_ms_per_step": {k: round(1e3 * v[0] / steps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}}
+           "by_kernel_ms_per_step": {k: round(1e3 * v[0] / steps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]},
+           # algorithmic GB/s of the kernels whose byte count is known, largest first
+           "by_kernel_gbps": {k: round(v[2] / v[0] / 1e9) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:16] if v[4] and v[2]}}
     if fl:
         out["tflops"] = fl / t / 1e12
         out["mfma_frac"] = fl / t / MFMA_PEAK_FLOPS
