@@ -228,19 +228,33 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
 
     // rows before the first step's new rows: stride 1 needs {-1, 0}, stride 2 needs {-1}
     const int base0 = STRIDE == 1 ? 1 : 0;
+    // Small images: the rows in front of the first step and the first step's rows fit the staging registers together, and
+    // then the next image's first rows are requested while this image's last step is convolved (otherwise every image of a
+    // one-step geometry would wait out a memory round trip with nothing to do).
+    const int cnt0 = base0 + 1 + RS * NEW;
+    const bool merged = cnt0 * Ws * 8 <= CONV_MAXI * 256;
+    bool have = false;                                   // the registers already hold this image's first rows
+    const long img_off = (long)cb * 64 + chunk * 8;
     for (int n = n_first; n < gm.N; n += n_step) {       // images of this workgroup; statistics stay in registers
-    img = src + (long)n * Hs * Ws * C + cb * 64 + chunk * 8;
     __syncthreads();                                     // the previous image's ring and staging are no longer read
-    fetch(-1, base0 + 1);
-    commit(-1, base0 + 1);
-    fetch(base0, RS * NEW);
+    if (merged) {
+        if (!have) { img = src + (long)n * Hs * Ws * C + img_off; fetch(-1, cnt0); }
+        commit(-1, cnt0);
+        have = false;
+    } else {
+        img = src + (long)n * Hs * Ws * C + img_off;
+        fetch(-1, base0 + 1);
+        commit(-1, base0 + 1);
+        fetch(base0, RS * NEW);
+    }
     const int nsteps = (Hd + RS - 1) / RS;
     const int P_full = RS * Wd;
     for (int st = 0; st < nsteps; ++st) {
         const int first_new = base0 + st * RS * NEW;
-        commit(first_new, RS * NEW);
+        if (!(merged && st == 0)) commit(first_new, RS * NEW);
         __syncthreads();
         if (st + 1 < nsteps) fetch(first_new + RS * NEW, RS * NEW);
+        else if (merged && n + n_step < gm.N) { img = src + (long)(n + n_step) * Hs * Ws * C + img_off; fetch(-1, cnt0); have = true; }
         const int row0 = st * RS;
         const int rows_here = (row0 + RS <= Hd) ? RS : Hd - row0;
         const int P = rows_here * Wd;
@@ -672,6 +686,7 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             return (size_t)nr * (rg.Ws + 2) * PSB + (size_t)rs * rg.Wd * 128 + 128 * sizeof(float);
         };
         int cap = 196 / rg.Wd; if (cap < 1) cap = 1; if (cap > rg.Hd) cap = rg.Hd;
+
         int best = 0, best_steps = 1 << 30;
         for (int rs = cap; rs >= 1; --rs) {
             if ((long)rs * st * rg.Ws * 8 > CONV_MAXI * 256 || lds_of(rs) > 72 * 1024) continue;
