@@ -521,7 +521,13 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
     const int hb_lo = ((px_lo >> 3) * stride) * IW + (px_lo & 7) * stride;
     const int hb_hi = ((px_hi >> 3) * stride) * IW + (px_hi & 7) * stride;
 
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // The tiles of the next item travel global -> registers while the current one is multiplied (a tile is only 9 MFMAs of
+    // work per wave, far less than a memory round trip); BatchNorm + ReLU is applied when the registers go to LDS, so the
+    // loads are not waited for where they are issued.
+    constexpr int MAXH = (MAX_HALO * 8 + 255) / 256;               // halo chunks per thread (5 at stride 2, 2 at stride 1)
+    bf16x8 r_out, r_in[MAXH];
+    unsigned in_ok = 0;                                            // bit k: r_in[k] came from inside the image
+    auto fetch = [&](int item) {
         uint32_t n, tr, trow, tcol;
         fdivmod((uint32_t)item, fd_tiles, n, tr);
         fdivmod(tr, fd_tw, trow, tcol);
@@ -529,29 +535,46 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
         {   // dOut tile: thread -> pixel tid/8, chunk tid%8
             const int px = tid >> 3;
             const int ho = ho0 + (px >> 3), wo = wo0 + (px & 7);
-            bf16x8 v = zero8();
-            if (ho < Ho && wo < Wo) v = *reinterpret_cast<const bf16x8*>(dout + (((long)n * Ho + ho) * Wo + wo) * C + cbase);
-            *reinterpret_cast<bf16x8*>(&Pt[(cgrp * 32 + rho32(px)) * 16 + chalf * 8]) = v;
+            r_out = zero8();
+            if (ho < Ho && wo < Wo) r_out = *reinterpret_cast<const bf16x8*>(dout + (((long)n * Ho + ho) * Wo + wo) * C + cbase);
         }
-        for (int i = tid; i < halo * 8; i += 256) {
-            const uint32_t hp = (uint32_t)i >> 3;
-            uint32_t hr, hc;
-            fdivmod(hp, fd_iw, hr, hc);
-            const int hi = ho0 * stride - 1 + (int)hr, wi = wo0 * stride - 1 + (int)hc;
-            bf16x8 v = zero8();
-            if (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) {
-                v = *reinterpret_cast<const bf16x8*>(in + (((long)n * Hi + hi) * Wi + wi) * C + cbase);
-                if (affine) {
+        in_ok = 0;
+#pragma unroll
+        for (int k = 0; k < MAXH; ++k) {
+            const int i = tid + k * 256;
+            r_in[k] = zero8();
+            if (i < halo * 8) {
+                const uint32_t hp = (uint32_t)i >> 3;
+                uint32_t hr, hc;
+                fdivmod(hp, fd_iw, hr, hc);
+                const int hi = ho0 * stride - 1 + (int)hr, wi = wo0 * stride - 1 + (int)hc;
+                if (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) {
+                    r_in[k] = *reinterpret_cast<const bf16x8*>(in + (((long)n * Hi + hi) * Wi + wi) * C + cbase);
+                    in_ok |= 1u << k;
+                }
+            }
+        }
+    };
+    if ((int)blockIdx.x < n_items) fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        *reinterpret_cast<bf16x8*>(&Pt[(cgrp * 32 + rho32(tid >> 3)) * 16 + chalf * 8]) = r_out;
+#pragma unroll
+        for (int k = 0; k < MAXH; ++k) {
+            const int i = tid + k * 256;
+            if (i < halo * 8) {
+                bf16x8 v = r_in[k];
+                if (affine && (in_ok >> k & 1)) {
                     float f[8];
                     unpack8(v, f);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] * sc[k] + sh[k], 0.f);
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f);
                     v = pack8(f);
                 }
+                *reinterpret_cast<bf16x8*>(&It[(cgrp * MAX_HALO + (i >> 3)) * 16 + chalf * 8]) = v;
             }
-            *reinterpret_cast<bf16x8*>(&It[(cgrp * MAX_HALO + hp) * 16 + chalf * 8]) = v;
         }
         __syncthreads();
+        if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);
         const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(&Pt[a_lo]));
         const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(&Pt[a_hi]));
         const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
