@@ -402,17 +402,29 @@ __global__ __launch_bounds__(256) void conv3x3g_dgrad2_kernel(const bf16* __rest
     const int ne = (Wi + 1) >> 1, no = Wi >> 1;       // even / odd output columns per row
     const int fe = (ne + 15) >> 4, fo = (no + 15) >> 4;
     const int nsteps = (Ho + R - 1) / R;
+    // (as in conv3x3g_rows_kernel: when row 0 and the first step's rows fit the staging registers together, the next image's
+    // first rows are requested while this image's last step is computed)
+    const bool merged = (1 + R) * Wo * 8 <= CONV_MAXI * 256;
+    bool have = false;
+    const long img_off = (long)cb * 64 + chunk * 8;
     for (int n = n_first; n < gm.N; n += n_step) {
-        img = dy + (long)n * Ho * Wo * C + cb * 64 + chunk * 8;
         __syncthreads();
-        fetch(0, 1);
-        commit(0, 1);
-        fetch(1, R);
+        if (merged) {
+            if (!have) { img = dy + (long)n * Ho * Wo * C + img_off; fetch(0, 1 + R); }
+            commit(0, 1 + R);
+            have = false;
+        } else {
+            img = dy + (long)n * Ho * Wo * C + img_off;
+            fetch(0, 1);
+            commit(0, 1);
+            fetch(1, R);
+        }
         for (int st = 0; st < nsteps; ++st) {
             const int y0 = st * R;
-            commit(y0 + 1, R);
+            if (!(merged && st == 0)) commit(y0 + 1, R);
             __syncthreads();
             if (st + 1 < nsteps) fetch(y0 + R + 1, R);
+            else if (merged && n + n_step < gm.N) { img = dy + (long)(n + n_step) * Ho * Wo * C + img_off; fetch(0, 1 + R); have = true; }
             int out_rows = 2 * R;
             if (2 * y0 + out_rows > Hi) out_rows = Hi - 2 * y0;
             for (int rr = 0; rr < out_rows; ++rr) {
