@@ -291,6 +291,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     float* sh_s = sc_s + K;
     float* red = sh_s + K;                      // [2][NB]
     float* de_s = red + 2 * NB;                 // [K], BNB only (sc_s = alpha, sh_s = beta, de_s = delta)
+    // GATE only: this wave's copy of the gate rows of the (at most two) images its current tile touches, refreshed once per
+    // tile -- read at the point of use from global memory the gate cost a cache round trip in every k-step
+    // (it lives in the wave's output staging buffer: the gate is read in the k loop, the staging buffer in the tile epilogue)
+    float* gl = reinterpret_cast<float*>(stage);               // [2][K]: 8*K bytes <= 16*SRS since K <= 2*NB + 16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -347,11 +351,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     const float* c_gate[2] = {nullptr, nullptr};
     auto c_rows = [&]() {
         if (GATE) {
+            if (c_tile >= row_tiles) return;
+            long m0 = c_tile * 32, m1 = m0 + 31;
+            if (m1 >= M) m1 = M - 1;
+            const uint32_t i0 = fdiv((uint32_t)m0, dv.gate), i1 = fdiv((uint32_t)m1, dv.gate);      // i1 <= i0 + 1 (gate_group >= 32)
+            __builtin_amdgcn_wave_barrier();                    // the previous tile's reads of gl are done
+            for (int c = lane; c < K / 2; c += 64) {            // 2 rows x K floats as float4 chunks
+                const int r = c >= K / 4, cc = c - r * (K / 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.a_gate + (long)(r ? i1 : i0) * K + cc * 4);
+                *reinterpret_cast<f32x4*>(gl + r * K + cc * 4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                long m = c_tile * 32 + j * 16 + fr;
+                long m = m0 + j * 16 + fr;
                 if (m >= M) m = M - 1;
-                c_gate[j] = p.a_gate + (long)fdiv((uint32_t)m, dv.gate) * K;
+                c_gate[j] = gl + (fdiv((uint32_t)m, dv.gate) - i0) * K;
             }
         }
     };
@@ -753,7 +769,7 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
         else if (a->N % 128 == 0 && a->N <= 1024) nb = 128;     // wide layers with a short K (stage 4's first 1x1 conv): 128-column slices
         const bool fits = nb > 0 && a->K % 32 == 0 && a->K <= 320 && !a->c_f32 && a->M >= 8192 && a->ldc % 8 == 0 &&
                           (a->k0 == 0 || a->k0 % 8 == 0) && (a->n_split == 0 || (a->n_split % 8 == 0 && a->ldc0 % 8 == 0)) &&
-                          (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0));
+                          (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0 && a->gate_group >= 32 && a->K <= 4 * nb + 32));
         if (fits) {
             const int ni = nb / 16, waves = nb >= 128 ? 8 : 4;
             const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) +

@@ -212,7 +212,7 @@ def _stream_slice(N):
 def _gemm_kernel(a):
     """Which kernel stes_gemm dispatches to (the rule in stes_gemm.hip)."""
     stream_ok = (_stream_slice(a.N) and a.K % 32 == 0 and a.K <= 320 and not a.c_f32 and a.M >= 8192
-                 and (not a.a_gate or a.N >= 64))
+                 and (not a.a_gate or (a.N >= 64 and a.gate_group >= 32)))
     if stream_ok:
         nb = _stream_slice(a.N)
         return "gemm_stream_kernel<%d, %d, %d>" % (nb // 16, 8 if nb >= 128 else 4, 2 if a.a_raw else (1 if a.a_gate else 0))
