@@ -36,8 +36,10 @@ template <int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv) {
     constexpr int NI = BN / 32;          // 16-wide n fragments per wave (wave covers BN/2 columns)
     constexpr int BLOADS = BN / 64;      // W-tile chunk loads per thread
-    __shared__ __attribute__((aligned(16))) bf16 As[2][BM * BK];
-    __shared__ __attribute__((aligned(16))) bf16 Bs[2][BN * BK];
+    // two k-steps of 32 per barrier (KB = 2 tiles per buffer): the barrier and the LDS round trip are paid once per 32 MFMAs
+    constexpr int KB = 2;
+    __shared__ __attribute__((aligned(16))) bf16 As[2][KB * BM * BK];
+    __shared__ __attribute__((aligned(16))) bf16 Bs[2][KB * BN * BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
     const bf16* __restrict__ W = (const bf16*)p.W;
     const int K = p.K, N = p.N;
     const long M = p.M;
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (K + KB * BK - 1) / (KB * BK);
     const bool has_affine = p.a_scale != nullptr;
     const bool has_gate = p.a_gate != nullptr;
     const bool pro = has_affine || has_gate;
@@ -104,27 +106,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        bf16x8 ra[2], rb[BLOADS];
+        bf16x8 ra[KB][2], rb[KB][BLOADS];
         auto gload = [&](int ks) {
-            const int k = ks * BK + ld_chunk * 8;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (ri[h].a != nullptr && k < K) {
-                    const bf16* src = (k < p.k0) ? ri[h].a0 + k : ri[h].a + k;
-                    ra[h] = *reinterpret_cast<const bf16x8*>(src);
-                } else {
-                    ra[h] = zero8();
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k = (ks * KB + kb) * BK + ld_chunk * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (ri[h].a != nullptr && k < K) {
+                        const bf16* src = (k < p.k0) ? ri[h].a0 + k : ri[h].a + k;
+                        ra[kb][h] = *reinterpret_cast<const bf16x8*>(src);
+                    } else {
+                        ra[kb][h] = zero8();
+                    }
                 }
-            }
 #pragma unroll
-            for (int h = 0; h < BLOADS; ++h)
-                rb[h] = (wrow[h] != nullptr && k < K) ? *reinterpret_cast<const bf16x8*>(wrow[h] + k) : zero8();
+                for (int h = 0; h < BLOADS; ++h)
+                    rb[kb][h] = (wrow[h] != nullptr && k < K) ? *reinterpret_cast<const bf16x8*>(wrow[h] + k) : zero8();
+            }
         };
         auto lstore = [&](int ks, int buf) {
-            const int k = ks * BK + ld_chunk * 8;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int k = (ks * KB + kb) * BK + ld_chunk * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                bf16x8 v = ra[h];
+                bf16x8 v = ra[kb][h];
                 if (pro && ri[h].a != nullptr && k < K) {
                     float f[8];
                     unpack8(v, f);
@@ -149,13 +156,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
                     v = pack8(f);
                 }
                 const int row = ld_row + h * 64;
-                *reinterpret_cast<bf16x8*>(&As[buf][row * BK + swz(row, ld_chunk) * 8]) = v;
+                *reinterpret_cast<bf16x8*>(&As[buf][kb * BM * BK + row * BK + swz(row, ld_chunk) * 8]) = v;
             }
 #pragma unroll
             for (int h = 0; h < BLOADS; ++h) {
                 const int row = ld_row + h * 64;
-                *reinterpret_cast<bf16x8*>(&Bs[buf][row * BK + swz(row, ld_chunk) * 8]) = rb[h];
+                *reinterpret_cast<bf16x8*>(&Bs[buf][kb * BN * BK + row * BK + swz(row, ld_chunk) * 8]) = rb[kb][h];
             }
+          }
         };
 
         gload(0);
@@ -164,22 +172,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         for (int ks = 0; ks < nk; ++ks) {
             const int buf = ks & 1;
             if (ks + 1 < nk) gload(ks + 1);
-            bf16x8 fa[NI], fb[4];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int row = wn * (BN / 2) + i * 16 + fr;
-                fa[i] = *reinterpret_cast<const bf16x8*>(&Bs[buf][row * BK + swz(row, fq) * 8]);
+            for (int kb = 0; kb < KB; ++kb) {
+                bf16x8 fa[NI], fb[4];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = wn * (BN / 2) + i * 16 + fr;
+                    fa[i] = *reinterpret_cast<const bf16x8*>(&Bs[buf][kb * BN * BK + row * BK + swz(row, fq) * 8]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 64 + j * 16 + fr;
+                    fb[j] = *reinterpret_cast<const bf16x8*>(&As[buf][kb * BM * BK + row * BK + swz(row, fq) * 8]);
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wm * 64 + j * 16 + fr;
-                fb[j] = *reinterpret_cast<const bf16x8*>(&As[buf][row * BK + swz(row, fq) * 8]);
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (ks + 1 < nk) lstore(ks + 1, buf ^ 1);
             __syncthreads();
         }
