@@ -64,7 +64,7 @@ typedef struct {
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
 /* dW[N1,N2] += P[M,N1]^T * pro(Q)[M,N2]   (f32 atomics; caller zeroes dW)
- * dbias[N1] += column sums of P (optional).  pro() and the row mapping apply to Q only.
+ * dbias[N1] += column sums of P (optional; of the prologue's result when P has one).  pro() and the row mapping apply to Q only.
  * Replaces: autograd weight gradients of the same layers.                               */
 typedef struct {
     const uint16_t* P;  int64_t ldp;
@@ -77,6 +77,10 @@ typedef struct {
     float* dbias;
     int32_t perm_fold;    /* > 0: output column c < perm_fold is stored at column dest(c) (gated-shift interleave) */
     int64_t M; int32_t N1; int32_t N2;
+    /* optional BatchNorm-backward prologue on P (64-wide tile only: N1 <= 64 or N2 <= 64): with p_raw [M,N1] (ldp), the raw
+     * tensor under the BatchNorm whose output gradient is P, the operand is bf16(bn_alpha*P + bn_beta*p_raw + bn_delta) --
+     * the tensor stes_bn_bwd_apply would have written.  For layers with no input gradient (the stem).                   */
+    const uint16_t* p_raw; const float* bn_alpha; const float* bn_beta; const float* bn_delta;
 } stes_wgrad_args;
 int stes_wgrad(const stes_wgrad_args* a, void* stream);
 

@@ -602,10 +602,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
+    // BatchNorm-backward prologue on P (small tile only: its 24 coefficient registers do not fit the capped 128-tile)
+    const bf16* __restrict__ PR = T == 64 ? (const bf16*)p.p_raw : nullptr;
+    float pal[8], pbe[8], pde[8];
+    if (T == 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = PR != nullptr && c1_ok;
+            pal[i] = on ? p.bn_alpha[c1 + i] : 1.f; pbe[i] = on ? p.bn_beta[c1 + i] : 0.f; pde[i] = on ? p.bn_delta[c1 + i] : 0.f;
+        }
+    }
     float qsc[8], qsh[8];      // this thread's 8 columns of the prologue's scale / shift
 #pragma unroll
     for (int i = 0; i < 8; ++i) { qsc[i] = (has_affine && c2_ok) ? p.q_scale[c2 + i] : 1.f; qsh[i] = (has_affine && c2_ok) ? p.q_shift[c2 + i] : 0.f; }
-    bf16x8 rp[LOADS], rq[LOADS];
+    bf16x8 rp[LOADS], rq[LOADS], rr[T == 64 ? LOADS : 1];
     long qm[LOADS];   // logical row of each staged q chunk (for the gate lookup)
     auto gload = [&](long mb) {
 #pragma unroll
@@ -614,6 +624,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             qm[h] = m;
             if (m < m_end) {
                 rp[h] = c1_ok ? *reinterpret_cast<const bf16x8*>(P + m * p.ldp + c1) : zero8();
+                if (T == 64 && PR) rr[h] = c1_ok ? *reinterpret_cast<const bf16x8*>(PR + m * p.ldp + c1) : zero8();
                 long src = m;
                 if (p.map_stride > 1) {
                     uint32_t n, rem, ho, wo;
@@ -652,6 +663,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 v = pack8(f);
             }
             *reinterpret_cast<bf16x8*>(&Qs[buf][rho(row) * LDT + lc * 8]) = v;
+            if (T == 64 && PR && qm[h] < m_end && c1_ok) {
+                float f[8], r[8];
+                unpack8(rp[h], f);
+                unpack8(rr[h], r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = pal[i] * f[i] + pbe[i] * r[i] + pde[i];
+                rp[h] = pack8(f);
+            }
             *reinterpret_cast<bf16x8*>(&Ps[buf][rho(row) * LDT + lc * 8]) = rp[h];
             if (do_bias) {
 #pragma unroll
@@ -833,6 +852,8 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     STES_CHECK(a->k0 == 0 || (a->Q0 && a->k0 % 8 == 0 && a->ldq0 % 8 == 0), STES_ERR_ARG, "stes_wgrad: bad compact source");
     STES_CHECK(a->ldp >= (a->N1 + 7) / 8 * 8, STES_ERR_ARG, "stes_wgrad: ldp must cover N1 rounded up to 8 (pad the operand)");
     const bool big = a->N1 > 64 && a->N2 > 64;
+    STES_CHECK(!a->p_raw || (a->bn_alpha && a->bn_beta && a->bn_delta), STES_ERR_ARG, "stes_wgrad: the P prologue needs alpha/beta/delta");
+    STES_CHECK(!a->p_raw || !big, STES_ERR_UNSUPPORTED, "stes_wgrad: the P prologue exists for the 64-wide tile only (N1 <= 64 or N2 <= 64)");
     const int t = big ? 128 : 64;
     const int t1 = stes_div_up(a->N1, t), t2 = stes_div_up(a->N2, t);
     // split the rows so that the grid has ~1024 workgroups, at least 256 rows each

@@ -789,10 +789,9 @@ class Engine:
         # stem: dZ is masked by (X0 > 0) already and its sums against c0 were taken by s1.b1's backward
         bn0 = self.bn0
         bn0.bwd_finalize(self.M0)
-        dc0 = sc("dc0", self.M0 * 32)
-        lib.bn_bwd_apply(dZ, self.c0, self.M0, 32, bn0.coef, dc0)
         K = self.stem.K
-        lib.wgrad(dc0, self.patches, g(self.stem.w), self.M0, 32, K, ldq=32, lddw=K)
+        # the stem has no input gradient: its BatchNorm backward is applied in the weight-gradient kernel's operand prologue
+        lib.wgrad(dZ, self.patches, g(self.stem.w), self.M0, 32, K, ldq=32, lddw=K, bn_bwd=(self.c0, bn0.coef))
         main.wait_stream(self.side)                  # every gradient is final from here on (optimizer, next forward)
         if on_ready:
             on_ready(*self.buckets["rest"])

@@ -45,7 +45,8 @@ WgradArgs = _struct("WgradArgs", [
     ("q_scale", _P), ("q_shift", _P), ("q_relu", _I32), ("q_gate", _P), ("gate_group", _I32),
     ("map_stride", _I32), ("Ho", _I32), ("Wo", _I32), ("Hi", _I32), ("Wi", _I32),
     ("dW", _P), ("lddw", _I64), ("dbias", _P), ("perm_fold", _I32),
-    ("M", _I64), ("N1", _I32), ("N2", _I32)])
+    ("M", _I64), ("N1", _I32), ("N2", _I32),
+    ("p_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P)])
 
 BnBwdArgs = _struct("BnBwdArgs", [
     ("D", _P), ("mul", _P), ("add", _P), ("group", _I32),
@@ -252,8 +253,8 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
 
 
 def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0, k0=0,
-          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None, perm_fold=0):
-    """dW += P^T pro(Q); see stes_wgrad in include/stes.h."""
+          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None, perm_fold=0, bn_bwd=None):
+    """dW += P^T pro(Q); see stes_wgrad in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta)): BatchNorm backward on P."""
     a = WgradArgs()
     a.P, a.ldp = ptr(P), ldp if ldp is not None else N1
     a.Q, a.ldq = ptr(Q), ldq if ldq is not None else N2
@@ -265,8 +266,10 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
     a.dW, a.lddw, a.dbias = ptr(dW), lddw if lddw is not None else N2, ptr(dbias)
     a.perm_fold = perm_fold
     a.M, a.N1, a.N2 = M, N1, N2
+    if bn_bwd is not None:
+        a.p_raw, (a.bn_alpha, a.bn_beta, a.bn_delta) = ptr(bn_bwd[0]), [ptr(t) for t in bn_bwd[1]]
     if TIMING is not None:
-        _timed("wgrad_kernel<128, 8>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64, 4>", 2 * M * (N1 + N2), 2 * M * N1 * N2,
+        _timed("wgrad_kernel<128, 8>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64, 4>", 2 * M * (N1 + N2 + (N1 if bn_bwd else 0)), 2 * M * N1 * N2,
                lambda: check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad"))
         return
     check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")

@@ -171,3 +171,29 @@ def test_gemm_bn_backward_prologue_equals_apply_then_gemm(N, K):
     assert lib.gemm_streams(M, N, K)
     with pytest.raises(lib.StesError):
         lib.gemm(dD, dW_, C2, 4096, N, K, bn_bwd=(dR, coef, None))          # too few rows for the streaming kernel
+
+
+@pytest.mark.parametrize("N1,N2", [(32, 32), (64, 24), (32, 128)])
+def test_wgrad_bn_backward_prologue_equals_apply_then_wgrad(N1, N2):
+    """stes_wgrad with the BatchNorm-backward prologue on P (the stem's path: no input gradient, so no GEMM to do it)
+    against stes_bn_bwd_apply followed by the plain weight gradient, including the bias gradient."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(N1 * 5 + N2)
+    M = 9001
+    D, raw, Q = _bf(M, N1, g=g), _bf(M, N1, g=g), _bf(M, N2 + (-N2) % 8, g=g)
+    coef = [dev(torch.randn(N1, generator=g) * s) for s in (1.0, 0.3, 0.1)]
+    dD, dR, dQ = dev(D), dev(raw), dev(Q)
+    dc = torch.empty(M, N1, dtype=torch.bfloat16, device="cuda")
+    lib.bn_bwd_apply(dD, dR, M, N1, coef, dc)
+    ref, got = torch.zeros(N1, N2, device="cuda"), torch.zeros(N1, N2, device="cuda")
+    bref, bgot = torch.zeros(N1, device="cuda"), torch.zeros(N1, device="cuda")
+    ldq = Q.shape[1]
+    lib.wgrad(dc, dQ, ref, M, N1, N2, ldq=ldq, dbias=bref)
+    lib.wgrad(dD, dQ, got, M, N1, N2, ldq=ldq, dbias=bgot, bn_bwd=(dR, coef))
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((got - ref).abs().max()) <= 2e-3 * scale          # same operands; only the order of the fp32 atomics differs
+    assert float((bgot - bref).abs().max()) <= 2e-3 * (float(bref.abs().max()) + 1e-6)
+    if N2 > 64:
+        with pytest.raises(lib.StesError):
+            lib.wgrad(dD, dQ, got, M, 128, N2, ldq=ldq, bn_bwd=(dR, coef))
