@@ -66,6 +66,37 @@ def test_deeper_gru_eval_vs_oracle():
     np.testing.assert_allclose(loc, oloc, atol=2e-2)
 
 
+def test_deeper_gru_training_gradients_of_the_head_vs_oracle():
+    """-t deeper_gru (3 stacked bidirectional layers, reference train_e2e_spatial.py:379): one training forward/backward
+    against the fp32 oracle -- loss, and the gradients of every GRU tensor (the recurrence through all three layers) and of
+    the classifier.  Location targets are kept away from the L1 kink (see tools/gen_golden.py)."""
+    from oracle import stes_oracle as O
+    om, m = _pair("rny008_gsm", "deeper_gru", seed=8)
+    for mod in (om, m._model):
+        mod.train()
+        mod._pred_fine._dropout.p = 0.0
+    m._model.engine.drop_p = 0.0
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 4, 3, 64, 64, generator=g)
+    label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+    od = om(x)
+    with torch.no_grad():
+        s_ = od["loc_feat"].sigmoid()
+        xy = (s_ + torch.where(torch.rand(2, 4, 2, generator=g) < 0.5, -0.2, 0.2)).clamp(0.0, 1.0)
+    ol, _, _ = O.stes_loss(od["im_feat"], od["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+    ol.backward()
+    out = m.train_step(x.cuda(), label.cuda(), xy.cuda(), lr=0.0, optimizer_step=False).cpu()
+    assert abs(float(out[0]) - float(ol.detach())) < 3e-2 * abs(float(ol.detach())), (out, ol)
+    og = {n: p.grad for n, p in om.named_parameters() if p.grad is not None}
+    worst = 0.0
+    for n, p in m._model.named_parameters():
+        if n.startswith("_pred_fine"):
+            r = rel(p.grad.cpu(), og[n])
+            worst = max(worst, r)
+            assert r < 0.12, (n, r)          # bf16 features feed the head: measured 0.02-0.06
+    print("deeper_gru head gradients, worst rel. L2 vs fp32 oracle: %.3f" % worst)
+
+
 def test_short_clip_is_padded_then_unpadded_like_reference():
     """T < clip_len: frames are zero-padded for the backbone and the heads run on the true length
     (reference train_e2e_spatial.py:423-442)."""
