@@ -93,7 +93,7 @@ def test_deeper_gru_training_gradients_of_the_head_vs_oracle():
         if n.startswith("_pred_fine"):
             r = rel(p.grad.cpu(), og[n])
             worst = max(worst, r)
-            assert r < 0.12, (n, r)          # bf16 features feed the head: measured 0.02-0.06
+            assert r < 0.05, (n, r)          # bf16 features and weights feed the head: measured 0.015
     print("deeper_gru head gradients, worst rel. L2 vs fp32 oracle: %.3f" % worst)
 
 
