@@ -32,14 +32,24 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const stes_gru_args p
         const int nk = H / 32;
         const int brow = b0 + fr;
         const bf16* arow = (brow < B) ? y + ((long)brow * T + tprev) * 2 * H + dir * H : nullptr;
-        for (int ks = wave; ks < nk; ks += 4) {
-            const int k = ks * 32 + fq * 8;
-            const bf16x8 fa = arow ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+        // a step is a few microseconds of pure latency: all loads of six k-steps are issued before the first MFMA needs one
+        constexpr int U = 6;
+        for (int ks0 = wave; ks0 < nk; ks0 += 4 * U) {
+            bf16x8 fa[U], fb[U][3];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(whh + ((long)g * H + j0 + fr) * H + k);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[g], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + 4 * u;
+                const int k = ks * 32 + fq * 8;
+                const bool on = ks < nk;
+                fa[u] = (on && arow) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    fb[u][g] = on ? *reinterpret_cast<const bf16x8*>(whh + ((long)g * H + j0 + fr) * H + k) : zero8();
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], fb[u][g], acc[g], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -94,12 +104,24 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const stes_gru_args p
         const int K = 3 * H, nk = K / 32;
         const int brow = b0 + fr;
         const bf16* arow = (brow < B) ? dgh_all + (((long)dir * T + tnext) * B + brow) * K : nullptr;
-        for (int ks = wave; ks < nk; ks += 4) {
-            const int k = ks * 32 + fq * 8;
-            const bf16x8 fa = arow ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
-            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(whhT + (long)(j0 + fr) * K + k);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        // loads of nine k-steps in flight together, three independent accumulator chains (see the forward step)
+        constexpr int U = 9;
+        f32x4 part[3] = {acc, acc, acc};
+        for (int ks0 = wave; ks0 < nk; ks0 += 4 * U) {
+            bf16x8 fa[U], fb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + 4 * u;
+                const int k = ks * 32 + fq * 8;
+                const bool on = ks < nk;
+                fa[u] = (on && arow) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+                fb[u] = on ? *reinterpret_cast<const bf16x8*>(whhT + (long)(j0 + fr) * K + k) : zero8();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) part[u % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], fb[u], part[u % 3], 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = part[0][r] + part[1][r] + part[2][r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
