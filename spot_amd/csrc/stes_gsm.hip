@@ -724,7 +724,9 @@ extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float
     const int nch = gm.fold / 8;
     GateTile gt;
     gt.PS = (nch >= 4 && nch % 2 == 0) ? nch + 1 : nch;         // odd 16-byte stride: conflict-free ds_read_b128 across positions
-    const int wb = 1, spr = stes_div_up(gm.W, wb);
+    // one output per thread (WB = 1): measured at least as fast as four-wide strips at every stage once the channel loop
+    // unrolls, and it keeps more threads busy on the small images; the WB = 4 form of the kernel is not instantiated
+    const int spr = gm.W;
     // + 4 positions: the last strip of a ragged row may read (and discard) past the tile's end
     auto slot = [&](int t) { return (size_t)((t + 2) * (gm.W + 2) + 4) * gt.PS * 16; };
     auto lds_of = [&](int t) { return 3 * slot(t) + (size_t)gm.fold * 2 * sizeof(float); };
@@ -760,13 +762,12 @@ extern "C" int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float
                            (const uint32_t*)wt, b3d, gate, gm, gt);                                                                \
     } while (0)
     // the channel counts of RegNet-Y 800MF's gated shifts get their own instantiation, anything else the generic loop
-    if (gm.fold == 8) { if (wb == 4) GATE_CASE(4, 4, 4); else GATE_CASE(4, 1, 4); }
-    else if (wb == 4) {
-        if (half == 8) GATE_CASE(8, 4, 8); else if (half == 16) GATE_CASE(8, 4, 16); else GATE_CASE(8, 4, 0);
-    } else {
-        if (half == 8) GATE_CASE(8, 1, 8); else if (half == 16) GATE_CASE(8, 1, 16); else if (half == 40) GATE_CASE(8, 1, 40); else if (half == 96) GATE_CASE(8, 1, 96);
-        else GATE_CASE(8, 1, 0);
-    }
+    if (gm.fold == 8) GATE_CASE(4, 1, 4);
+    else if (half == 8) GATE_CASE(8, 1, 8);
+    else if (half == 16) GATE_CASE(8, 1, 16);
+    else if (half == 40) GATE_CASE(8, 1, 40);
+    else if (half == 96) GATE_CASE(8, 1, 96);
+    else GATE_CASE(8, 1, 0);
 #undef GATE_CASE
     STES_LAUNCH_CHECK();
     return STES_OK;
