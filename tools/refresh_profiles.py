@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rebuild the round's files under profiles/ from the rocprofv3 output a GPU run left under gpurun_out/
+"""Rebuild the files under profiles/ from the rocprofv3 output a GPU run left under gpurun_out/
 (prof_e: the step as benchmarked; prof_es: --serial; pmc_fetch_e / pmc_write_e: counter passes; r1_e_bench.json)."""
 import json
 import os
@@ -31,10 +31,10 @@ note_o = (f"Command: `{cmd}` (4 steps traced). bench.py un-profiled: {d['ms_per_
           f"are in `profiles/r1_e_serial_kernel_stats.md`.")
 for src, dst, title, note in (
         ("gpurun_out/prof_es/r1es_kernel_stats.csv", "profiles/r1_e_serial_kernel_stats.md",
-         "Round 1 (e), serial launches: full-size training step, weight-gradient kernels in program order on the main stream "
+         "Profile (e), serial launches: full-size training step, weight-gradient kernels in program order on the main stream "
          "(B=16, T=64, 224p, 1 MI355X)", note_s),
         ("gpurun_out/prof_e/r1e_kernel_stats.csv", "profiles/r1_e_kernel_stats.md",
-         "Round 1 (e): full-size training step as benchmarked, weight-gradient kernels on a side stream beside the input-gradient "
+         "Profile (e): full-size training step as benchmarked, weight-gradient kernels on a side stream beside the input-gradient "
          "chain (B=16, T=64, 224p, 1 MI355X)", note_o)):
     with open(dst, "w") as fp:
         subprocess.run([sys.executable, "tools/prof_summary.py", src, "--steps", "4", "--title", title, "--note", note], stdout=fp, check=True)
