@@ -9,8 +9,9 @@ from pre-decoded clips.  `frame_dir` holds shards `train_*.npz` / `val_*.npz` wi
     label int64 [n, clip_len]            0 = background
     xy    float32 [n, clip_len, 2]       event location in [0, 1]
 
-or is the literal string `synthetic[:n_clips]`.  Validation mAP needs the dataset JSON files and the reference's
-scoring code around this path; this driver selects the best epoch by validation loss (`--criterion loss`).
+or is the literal string `synthetic[:n_clips]`.  `--criterion map` (best epoch by validation mAP, from `--start_val_epoch`
+on) additionally needs whole validation videos: `val.json` in the reference's label format (data/<dataset>/val.json) and
+`val_videos/<video>.npy`, uint8 [num_frames, 3, H, W], which are memory-mapped; `synthetic` makes two random videos.
 
     python -m spot_amd.train DATASET FRAME_DIR -m rny008_gsm -t gru --clip_len 64 --batch_size 16 --predict_location -s DIR
 """
@@ -49,6 +50,7 @@ def get_args(argv=None):
     p.add_argument("--resume", action="store_true")
     p.add_argument("--predict_location", action="store_true")
     p.add_argument("--criterion", choices=["map", "loss"], default="loss")
+    p.add_argument("--start_val_epoch", type=int, default=30)
     p.add_argument("--time_backward", action="store_true")
     p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
     p.add_argument("--device", type=str, default="cuda")
@@ -108,6 +110,25 @@ def get_loaders(args, num_classes):
     if not tr or not va:
         raise FileNotFoundError(f"no train_*.npz / val_*.npz shards in {args.frame_dir}")
     return ClipShards(tr, bs), ClipShards(va, bs)
+
+
+def get_val_videos(args, classes):
+    """The whole-video validation set of `--criterion map` (reference train_e2e_spatial.py:888-904: clips of clip_len, no
+    overlap)."""
+    from .evaluate import VideoClipDataset
+    if args.frame_dir.startswith("synthetic"):
+        g = torch.Generator().manual_seed(2)
+        names, labels, frames = sorted(classes), [], {}
+        for v, n in (("synthetic0", 3 * args.clip_len - 7), ("synthetic1", 2 * args.clip_len)):
+            ev = [{"frame": int(f), "label": names[int(f) % len(names)], "xy": torch.rand(2, generator=g).tolist()}
+                  for f in sorted(torch.randperm(n, generator=g)[: max(2, n // 40)].tolist())]
+            labels.append({"video": v, "num_frames": n, "fps": 25, "events": ev})
+            frames[v] = torch.randint(0, 256, (n, 3, args.crop_dim, args.crop_dim), generator=g, dtype=torch.uint8)
+    else:
+        with open(os.path.join(args.frame_dir, "val.json")) as fp:
+            labels = json.load(fp)
+        frames = {l["video"]: np.load(os.path.join(args.frame_dir, "val_videos", l["video"] + ".npy"), mmap_mode="r") for l in labels}
+    return VideoClipDataset(classes, labels, frames, args.clip_len, overlap_len=0)
 
 
 def load_classes(args):
@@ -189,7 +210,7 @@ def store_config(file_path, args, num_epochs, classes):
               "temporal_arch": args.temporal_arch, "clip_len": args.clip_len, "batch_size": args.batch_size, "crop_dim": args.crop_dim,
               "num_epochs": num_epochs, "warm_up_epochs": args.warm_up_epochs, "learning_rate": args.learning_rate,
               "predict_location": args.predict_location, "pred_loc_arch": args.pred_loc_arch, "time_backward": args.time_backward,
-              "acc_grad_iter": args.acc_grad_iter, "criterion": args.criterion}
+              "acc_grad_iter": args.acc_grad_iter, "criterion": args.criterion, "start_val_epoch": args.start_val_epoch}
     with open(file_path, "w") as fp:
         json.dump(config, fp, indent=2, sort_keys=True)
 
@@ -203,8 +224,6 @@ def clear_files(dir_name, re_str):
 # ---------------------------------------------------------------------------------------------------------------- main
 def main(args):
     from .e2e import E2EModel
-    if args.criterion == "map":
-        raise NotImplementedError("validation mAP needs the dataset JSONs and scoring code around this path; use --criterion loss")
     assert args.batch_size % args.acc_grad_iter == 0
     classes = load_classes(args)
     model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
@@ -214,7 +233,8 @@ def main(args):
     optimizer, scaler = model.get_optimizer({"lr": args.learning_rate})
     num_steps_per_epoch = len(train_loader) // args.acc_grad_iter
     num_epochs, lr_scheduler = get_lr_scheduler(args, optimizer, num_steps_per_epoch)
-    losses, best_epoch, best_criterion = [], None, float("inf")
+    val_videos = get_val_videos(args, classes) if args.criterion == "map" else None
+    losses, best_epoch, best_criterion = [], None, (-0.1 if args.criterion == "map" else float("inf"))
     epoch = 0
     if args.resume:
         epoch, losses, best_epoch, best_criterion = load_from_save(args, model, optimizer, scaler, lr_scheduler)
@@ -225,10 +245,19 @@ def main(args):
         val_loss = model.epoch(val_loader, acc_grad_iter=args.acc_grad_iter)
         print("Epoch {}: train cls {:.5f} loc {:.5f} sum {:.5f} | val cls {:.5f} loc {:.5f} sum {:.5f}".format(
             epoch, train_loss["cls"], train_loss["loc"], train_loss["sum"], val_loss["cls"], val_loss["loc"], val_loss["sum"]))
-        if val_loss["sum"] < best_criterion:
-            best_criterion, best_epoch = val_loss["sum"], epoch
-            print("New best epoch!")
-        losses.append({"epoch": epoch, "train": train_loss["sum"], "val": val_loss["sum"], "val_mAP": 0})
+        val_mAP = 0
+        if args.criterion == "loss":
+            if val_loss["sum"] < best_criterion:
+                best_criterion, best_epoch = val_loss["sum"], epoch
+                print("New best epoch!")
+        elif epoch >= args.start_val_epoch:                  # reference train_e2e_spatial.py:1158-1178
+            from .evaluate import evaluate
+            val_mAP = float(evaluate(model, val_videos, "VAL", classes, os.path.join(args.save_dir, "pred-val.{}".format(epoch)),
+                                     save_scores=False, predict_location=args.predict_location))
+            if val_mAP > best_criterion:
+                best_criterion, best_epoch = val_mAP, epoch
+                print("New best epoch!")
+        losses.append({"epoch": epoch, "train": train_loss["sum"], "val": val_loss["sum"], "val_mAP": val_mAP})
         with open(os.path.join(args.save_dir, "loss.json"), "w") as fp:
             json.dump(losses, fp, indent=2, sort_keys=True)
         torch.save(model.state_dict(), os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(epoch)))

@@ -271,3 +271,39 @@ def test_train_driver_runs_checkpoints_and_resumes(tmp_path):
     args = TR.get_args(["ds", str(shard_dir)] + base[2:-4] + ["-s", str(tmp_path / "run2"), "--num_classes", "6", "--num_epochs", "2"])
     _, losses3, _ = TR.main(args)
     assert len(losses3) == 2 and np.isfinite(losses3[1]["val"])
+
+
+def test_train_driver_selects_the_best_epoch_by_validation_map(tmp_path):
+    """--criterion map: from start_val_epoch on, whole validation videos go through evaluate() (the reference's
+    train_e2e_spatial.py:1158-1178 and :656-827); the metric lands in loss.json and the predictions beside it.  The
+    video directory format (val.json + val_videos/*.npy) gives the same numbers as the same data held in memory."""
+    import json
+    import os
+    from spot_amd import evaluate as EV, train as TR
+    base = ["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "gru", "--clip_len", "8", "--crop_dim", "64", "--batch_size", "2",
+            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path / "run"), "--num_classes", "6",
+            "--criterion", "map", "--start_val_epoch", "1", "--num_epochs", "2"]
+    args = TR.get_args(base)
+    model, losses, best = TR.main(args)
+    assert losses[0]["val_mAP"] == 0 and 0 <= losses[1]["val_mAP"] <= 1 and best == 1
+    pred = json.load(open(tmp_path / "run" / "pred-val.1.json"))
+    assert [p["video"] for p in pred] == ["synthetic0", "synthetic1"] and os.path.exists(tmp_path / "run" / "pred-val.1.recall.json.gz")
+    assert json.load(open(tmp_path / "run" / "loss.json"))[1]["val_mAP"] == losses[1]["val_mAP"]
+    # the same videos from files
+    classes = TR.load_classes(args)
+    mem = TR.get_val_videos(args, classes)
+    d = tmp_path / "data"
+    os.makedirs(d / "val_videos")
+    json.dump(mem.labels, open(d / "val.json", "w"))
+    for v, f in mem._frames.items():
+        np.save(d / "val_videos" / (v + ".npy"), f.numpy())
+    args.frame_dir = str(d)
+    disk = TR.get_val_videos(args, classes)
+    assert len(disk) == len(mem) == 6 and torch.equal(disk[4]["frame"], mem[4]["frame"]) and disk[4]["start"] == mem[4]["start"]
+    a = EV.accumulate(model, mem, 6, True)
+    b = EV.accumulate(model, disk, 6, True, batch_size=3)            # batch composition does not change a clip's scores
+    for v in a:
+        assert np.array_equal(a[v][1], b[v][1]) and a[v][1].min() == 1
+        assert np.allclose(a[v][0], b[v][0], atol=2e-3) and np.allclose(a[v][2], b[v][2], atol=2e-3)
+    m1 = EV.evaluate(model, mem, "VAL", classes, predict_location=True, quiet=True)
+    assert abs(m1 - losses[1]["val_mAP"]) < 1e-9                  # the best epoch's weights were restored

@@ -70,6 +70,118 @@ def test_postproc_bit_exact_vs_reference_golden(golden):
     assert np.array_equal(np.array([e["score"] for e in s[0]["events"]]), z["nms_scores"])
 
 
+def test_event_metrics_bit_exact_vs_reference_golden(golden):
+    """Temporal mAP and spatial AP tables on three synthetic videos (jittered detections, tied-score false alarms) equal
+    the reference's util/score.py outputs to the last bit."""
+    import copy
+    from spot_amd.util import postproc as P, score as S
+    z = golden("scores")
+    truth, pred = json.loads(str(z["truth"])), json.loads(str(z["pred"]))
+    truth0, pred0 = copy.deepcopy(truth), copy.deepcopy(pred)
+    nms = P.non_max_suppression_events(P.filter_events_by_score(copy.deepcopy(pred), 0.15), 3)
+    mAPs, tol = S.compute_mAPs(truth, nms, tolerances=[0, 1, 2, 4], quiet=True)
+    assert tol == list(z["tolerances"]) and np.array_equal(np.array(mAPs), z["mAPs"])
+    mt, mp = S.compute_mAPs_with_locations(truth, pred, quiet=True)
+    assert np.array_equal(np.array(mt), z["mAPs_t"]) and np.array_equal(np.array(mp), z["mAP_ps"])
+    assert truth == truth0 and pred == pred0                       # inputs are not modified
+    assert 0.02 < z["mAPs"][0] < z["mAPs"][-1] < 1 and 0 < z["mAP_ps"][0] < z["mAP_ps"][-1]   # a non-degenerate case
+    with pytest.raises(AssertionError, match="Video set mismatch"):
+        S.compute_mAPs(truth, pred[:2], quiet=True)
+    # one class, hand-checked: detections at ranks 1 and 3 hit -> precisions 1, 2/3 -> AP = (1 + 2/3) / 3 ground-truth events
+    t = {"v": [10, 20, 30]}
+    r = [("v", 10, 0.9, None), ("v", 50, 0.8, None), ("v", 21, 0.7, None)]
+    assert S.average_precision(r, t, tolerance=1) == (1 + 2 / 3) / 3
+    assert S.average_precision(r, t, tolerance=0) == 1 / 3
+
+
+def test_frame_statistics_and_event_lists_bit_exact_vs_reference_golden(golden):
+    """Frame error, F1 counts, argmax and high-recall event lists, windowed peak picking: equal to the reference's
+    util/eval.py outputs on two synthetic videos (supports of 1 and 2, labels on 15% of frames)."""
+    from spot_amd.util import eval as E
+    z = golden("eval")
+    classes = {c: i + 1 for i, c in enumerate(["serve", "receive", "set", "attack", "block", "score"])}
+
+    class DS:
+        videos = [("a", 90, 25.0), ("b", 57, 25.0)]
+
+        @staticmethod
+        def get_labels(video, with_locations=False):
+            lab = z["label_" + video]
+            return (lab, np.zeros((len(lab), 2), np.float32)) if with_locations else lab
+
+    pred = {v: (z["scores_" + v].copy(), z["support_" + v], z["loc_" + v]) for v in "ab"}
+    err, f1, ev, ev_hr, sc = E.process_frame_predictions_with_location(DS, classes, pred)
+    assert err.get() == float(z["err"]) and 0 < err.get() < 1
+    keys = [None] + list(range(1, 7))
+    assert np.array_equal(np.array([f1.tp_fp_fn(k) for k in keys]), z["counts"]) and z["counts"].min(0).max() > 0
+    assert np.array_equal(np.array([f1.get(k) for k in keys]), z["f1"])
+    assert ev == json.loads(str(z["events"])) and ev_hr == json.loads(str(z["events_hr"])) and len(ev_hr[0]["events"]) > len(ev[0]["events"]) > 10
+    assert sc == json.loads(str(z["mean_scores"]))
+    assert E.non_maximum_supression(ev_hr, 2) == json.loads(str(z["nms"]))
+    _, _, ev2, _, _ = E.process_frame_predictions(DS, classes, {v: (z["scores_" + v].copy(), z["support_" + v]) for v in "ab"})
+    assert ev2 == json.loads(str(z["events_noloc"])) and "xy" not in ev2[0]
+    with pytest.raises(AssertionError):                      # a frame no clip covered
+        E.process_frame_predictions(DS, classes, {"a": (z["scores_a"].copy(), np.zeros(90, np.int32))})
+
+
+def test_video_clip_layout_and_evaluate_with_a_stub_model(tmp_path):
+    """Clip starts, padding and stride follow the reference's video dataset; evaluate() recovers planted events."""
+    from spot_amd import evaluate as EV
+    classes = {"serve": 1, "set": 2}
+    labels = [{"video": "v0", "num_frames": 50, "fps": 25, "events": [{"frame": 7, "label": "serve", "xy": [0.25, 0.5]},
+                                                                      {"frame": 30, "label": "set", "xy": [0.75, 0.25]}]},
+              {"video": "v1", "num_frames": 21, "fps": 30, "events": [{"frame": 20, "label": "set", "xy": [0.5, 0.5]}]}]
+    frames = {}
+    for l in labels:                                         # frame f of a video holds f + 1 in every byte (0 = padding)
+        frames[l["video"]] = (torch.arange(1, l["num_frames"] + 1, dtype=torch.uint8).view(-1, 1, 1, 1).expand(-1, 3, 2, 2).contiguous())
+    ds = EV.VideoClipDataset(classes, labels, frames, clip_len=16, overlap_len=8)
+    starts = [s for v, s in ds._clips if v == "v0"]
+    assert starts == list(range(-5, 42, 8)) and [s for v, s in ds._clips if v == "v1"] == [-5, 3, 11]
+    c = ds[0]
+    assert c["start"] == -5 and c["frame"][:5].eq(0).all() and c["frame"][5, 0, 0, 0] == 1 and c["frame"][15, 0, 0, 0] == 11
+    last = ds[len(starts) - 1]
+    assert last["start"] == 35 and last["frame"][14, 0, 0, 0] == 50 and last["frame"][15].eq(0).all()
+    assert ds.videos == [("v0", 50, 25.0), ("v1", 21, 30.0)]
+    lab, loc = ds.get_labels("v0", with_locations=True)
+    assert lab[7] == 1 and lab[30] == 2 and lab.sum() == 3 and loc[30].tolist() == [0.75, 0.25]
+    ds2 = EV.VideoClipDataset(classes, labels, frames, clip_len=8, stride=2)
+    assert ds2[0]["start"] == -5 and ds2[1]["frame"][:, 0, 0, 0].tolist() == [7, 9, 11, 13, 15, 17, 19, 21]
+    assert ds2.videos[0] == ("v0", 25, 12.5) and ds2.labels[0]["events"][0]["frame"] == 3 and labels[0]["events"][0]["frame"] == 7
+    assert sorted(b["start"][0] for r in range(2) for b in ds.batches(4, r, 2)) == sorted(ds[i]["start"] for i in range(0, len(ds), 4))
+
+    truth = {l["video"]: {e["frame"]: e for e in l["events"]} for l in labels}
+
+    class Stub:                                              # reads the frame number back from the pixels
+        def predict(self, clip):
+            B, T = clip.shape[:2]
+            scores, loc = np.zeros((B, T, 3), np.float32), np.zeros((B, T * 2), np.float32)
+            scores[..., 0] = 1
+            for b in range(B):
+                vid = self.videos[b]
+                for t in range(T):
+                    e = truth[vid].get(int(clip[b, t, 0, 0, 0]) - 1)
+                    if e is not None:
+                        scores[b, t] = 0.1
+                        scores[b, t, classes[e["label"]]] = 0.8
+                        loc[b, 2 * t:2 * t + 2] = e["xy"]
+            return scores.argmax(-1), scores, loc
+
+    stub = Stub()
+    orig = ds.batches
+
+    def batches(*a, **k):
+        for b in orig(*a, **k):
+            stub.videos = b["video"]
+            yield b
+    ds.batches = batches
+    out = EV.evaluate(stub, ds, "VAL", classes, save_pred=str(tmp_path / "pred"), predict_location=True, quiet=True)
+    assert abs(out - 1.0) < 1e-5                           # all three events found at the exact frame and pixel
+    ev = json.load(open(tmp_path / "pred.json"))
+    assert [(e["frame"], e["label"]) for e in ev[0]["events"]] == [(7, "serve"), (30, "set")] and ev[1]["events"][0]["frame"] == 20
+    assert ev[0]["events"][1]["xy"] == [0.75, 0.25] and os.path.exists(tmp_path / "pred.recall.json.gz")
+    assert EV.evaluate(stub, ds, "VAL", classes, predict_location=False, quiet=True) == 1.0
+
+
 def test_sliding_window_accumulator_and_sharding():
     from spot_amd import infer
     from spot_amd.util.postproc import ScoreAccumulator

@@ -259,6 +259,73 @@ def gen_postproc():
          nms_scores=np.array([e["score"] for e in s[0]["events"]], np.float64))
 
 
+def gen_scores():
+    """Event lists -> the reference's metrics (util/score.py compute_mAPs, compute_mAPs_with_locations)."""
+    import contextlib
+    import io
+    import json
+    rng = np.random.RandomState(11)
+    classes = ["serve", "receive", "set", "attack", "block", "score"]
+    truth, pred = [], []
+    for vi in range(3):
+        frames = np.sort(rng.choice(600, size=40, replace=False))
+        tev = [{"label": classes[rng.randint(6)], "frame": int(f), "xy": rng.rand(2).round(4).tolist()} for f in frames]
+        pev = []
+        for e in tev:                                  # detections near most events, with jitter in time and space
+            if rng.rand() < 0.85:
+                pev.append({"label": e["label"] if rng.rand() < 0.9 else classes[rng.randint(6)], "frame": int(e["frame"] + rng.randint(-3, 4)),
+                            "score": float(np.round(rng.rand() * 0.8 + 0.2, 3)), "xy": (np.array(e["xy"]) + rng.randn(2) * 0.01).tolist()})
+        for _ in range(25):                            # false alarms, some with tied scores
+            pev.append({"label": classes[rng.randint(6)], "frame": int(rng.randint(600)), "score": float(rng.choice([0.1, 0.2, 0.3, 0.5])),
+                        "xy": rng.rand(2).tolist()})
+        truth.append({"video": f"v{vi}", "events": tev})
+        pred.append({"video": f"v{vi}", "events": pev})
+    with contextlib.redirect_stdout(io.StringIO()):
+        import copy
+        nms = RSC.non_max_suppression_events(RSC.filter_events_by_score(copy.deepcopy(pred), 0.15), 3)
+        m1, tol1 = RSC.compute_mAPs(truth, nms, tolerances=[0, 1, 2, 4])
+        mt, mp = RSC.compute_mAPs_with_locations(truth, pred)
+    save("scores", truth=np.array(json.dumps(truth)), pred=np.array(json.dumps(pred)), mAPs=np.array(m1, np.float64),
+         tolerances=np.array(tol1), mAPs_t=np.array(mt, np.float64), mAP_ps=np.array(mp, np.float64))
+
+
+def gen_eval():
+    """Accumulated window scores -> frame error, F1 counts, event lists, windowed peak picking (reference util/eval.py)."""
+    import json
+    import util.eval as REV
+    rng = np.random.RandomState(5)
+    classes = {c: i + 1 for i, c in enumerate(["serve", "receive", "set", "attack", "block", "score"])}
+    lens = {"a": 90, "b": 57}
+    labels = {v: (rng.rand(n) < 0.15) * rng.randint(1, 7, n) for v, n in lens.items()}
+
+    class DS:
+        videos = [(v, n, 25.0) for v, n in lens.items()]
+
+        @staticmethod
+        def get_labels(video, with_locations=False):
+            lab = labels[video].astype(np.int32)
+            return (lab, np.zeros((len(lab), 2), np.float32)) if with_locations else lab
+
+    pred = {}
+    for v, n in lens.items():
+        support = rng.randint(1, 3, n).astype(np.int32)
+        logits = rng.randn(n, 7) * 1.5
+        logits[np.arange(n), labels[v]] += 2.0 * (rng.rand(n) < 0.8)
+        sm = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+        pred[v] = ((sm * support[:, None]).astype(np.float32), support, rng.rand(n, 2).astype(np.float32))
+    inputs = {v: [a.copy() for a in p] for v, p in pred.items()}
+    err, f1, ev, ev_hr, sc = REV.process_frame_predictions_with_location(DS, classes, pred)
+    err2, f12, ev2, ev_hr2, _ = REV.process_frame_predictions(DS, classes, {v: (p[0].copy(), p[1]) for v, p in inputs.items()})
+    nms = REV.non_maximum_supression(ev_hr, 2)
+    counts = np.array([f1.tp_fp_fn(k) for k in [None] + list(range(1, 7))], np.int64)
+    f1s = np.array([f1.get(k) for k in [None] + list(range(1, 7))], np.float64)
+    arrs = {}
+    for v, p in inputs.items():
+        arrs.update({f"scores_{v}": p[0], f"support_{v}": p[1], f"loc_{v}": p[2], f"label_{v}": labels[v].astype(np.int32)})
+    save("eval", err=np.array(err.get()), counts=counts, f1=f1s, events=np.array(json.dumps(ev)), events_hr=np.array(json.dumps(ev_hr)),
+         events_noloc=np.array(json.dumps(ev2)), nms=np.array(json.dumps(nms)), mean_scores=np.array(json.dumps(sc)), **arrs)
+
+
 class _RefComposite(nn.Module):
     """The reference's forward (train_e2e_spatial.py:416-455) over: oracle RegNet-Y with the
     REFERENCE's make_temporal_shift/GatedShift/_GSM inserted, reference GRUPrediction and
@@ -353,6 +420,12 @@ def gen_full(only=None):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]            # optional: names of the composite fixtures to regenerate (skips the module-level ones)
+    if not only or "scores" in only:
+        gen_scores()
+    if not only or "eval" in only:
+        gen_eval()
+    if "scores" in only or "eval" in only:
+        only = [t for t in only if t not in ("scores", "eval")] or ["-"]
     if not only:
         gen_gsm()
         gen_gated_shift()
