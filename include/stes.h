@@ -114,6 +114,16 @@ int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, co
  * stes_gemm (relu_mask, out_scale = 1/HW) + two stes_wgrad calls.
  * stes_sigmoid_bwd: out[i] = bf16(d[i] * g[i] * (1 - g[i])), the gradient at the sigmoid's input.                */
 int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream);
+/* Channel attention over a clip (reference model/modules.py:86-105 ChannelAttention, applied to the frame features at
+ * train_e2e_spatial.py:437-438): mean over the T frames (stes_chan_pool with HW = T) -> two bias-free stes_gemm calls
+ * (ReLU / sigmoid epilogues) -> stes_clip_gate_fwd: out[b,t,c] = x[b,t,c] * gate[b,c]   (x, out bf16 [B*T][C]; gate fp32).
+ * Backward, two calls of stes_clip_gate_bwd around the gate MLP's backward (stes_sigmoid_bwd, stes_gemm, stes_wgrad):
+ *   reduction (x, dgate given; gate, dpool, out NULL):  dgate[b,c] = sum_t (da + db)[b,t,c] * x[b,t,c]
+ *   apply (gate, dpool, out given; x, dgate NULL):      out[b,t,c] = (da + db)[b,t,c] * gate[b,c] + dpool[b,c]
+ * da, db (db may be NULL), out fp32 [B*T][C]; out may alias da; dpool already scaled by 1/T.             */
+int stes_clip_gate_fwd(const uint16_t* x, const float* gate, uint16_t* out, int B, int T, int C, void* stream);
+int stes_clip_gate_bwd(const float* da, const float* db, const uint16_t* x, const float* gate, const float* dpool,
+                       float* dgate, float* out, int B, int T, int C, void* stream);
 /* One pass over (c2, dA3 = gradient at the gated activation) per image: S [4][N][C] = sums over H,W of mask, dA3*mask,
  * mask*c2, dA3*mask*c2 with mask = [scale*c2 + shift > 0]; dgate [N][C] = gradient at the SE gate.  With the SE backward's
  * dpool, stes_se_bwd_bnsums turns S into the two BatchNorm-backward sums of conv2.bn (what stes_bn_bwd_reduce would give

@@ -350,6 +350,20 @@ class FCPrediction(nn.Module):
         return self._fc_out(x.reshape(b * t, -1)).view(b, t, -1)
 
 
+class ChannelAttention(nn.Module):
+    """reference model/modules.py:86-105: per clip, mean over the T frames -> Linear (no bias) -> ReLU -> Linear (no bias)
+    -> sigmoid -> every frame's features scaled by that per-channel gate."""
+
+    def __init__(self, feat_dim, reduction=8):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(feat_dim, feat_dim // reduction, bias=False), nn.ReLU(),
+                                nn.Linear(feat_dim // reduction, feat_dim, bias=False), nn.Sigmoid())
+
+    def forward(self, x):
+        y = self.fc[1](q(self.fc[0](q(x.mean(1)))))
+        return q(x * torch.sigmoid(self.fc[2](q(y))).unsqueeze(1))
+
+
 class GRUPrediction(nn.Module):
     """reference model/modules.py:20-36.  Parameters live in a torch.nn.GRU so the
     state-dict keys match; the arithmetic is the explicit recurrence above."""
@@ -444,10 +458,11 @@ MAX_GRU_HIDDEN_DIM = 768
 
 class Impl(nn.Module):
     def __init__(self, num_classes, feature_arch, temporal_arch, clip_len, modality="rgb",
-                 predict_location=False, pred_loc_arch="mlp", time_backward=False):
+                 predict_location=False, pred_loc_arch="mlp", time_backward=False, use_channel_attention=False):
         super().__init__()
         self.time_backward = time_backward
         self.feature_arch = feature_arch
+        self._use_channel_attention = use_channel_attention
         base = feature_arch.rsplit("_", 1)[0] if "_" in feature_arch else feature_arch
         if base not in ("rny002", "rny008"):
             raise NotImplementedError(feature_arch)
@@ -464,6 +479,8 @@ class Impl(nn.Module):
             self._require_clip_len = clip_len
         self._features = features
         self._feat_dim = feat_dim
+        # reference train_e2e_spatial.py:348-354
+        self._channel_attention = ChannelAttention(feat_dim, reduction=8) if use_channel_attention else nn.Identity()
         hidden = min(feat_dim, MAX_GRU_HIDDEN_DIM)
         if "gru" in temporal_arch:
             if temporal_arch in ("gru", "deeper_gru"):
@@ -495,6 +512,8 @@ class Impl(nn.Module):
                 x = torch.cat([x, pad], 1)
                 t = self._require_clip_len
         im = q(self._features(x.reshape(-1, c, h, w))).reshape(b, t, self._feat_dim)
+        if self._use_channel_attention:            # over the padded clip, before the padding is removed (:436-442)
+            im = self._channel_attention(im)
         if t != true_t:
             im = im[:, :true_t]
         loc = None

@@ -235,6 +235,45 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ d, const float* __r
     if (i < n) { const float gv = g[i]; out[i] = (bf16)(d[i] * gv * (1.f - gv)); }
 }
 
+// ---------------------------------------------------------------- per-clip channel gate over the frame features
+// out[b,t,c] = x[b,t,c] * gate[b,c]   (8 channels per thread)
+__global__ void clip_gate_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gate, bf16* __restrict__ out, int T, int C8,
+                                     long total8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        const float* g = gate + (row / T) * (long)C8 * 8 + c;
+        float v[8];
+        load8b(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= g[j];
+        store8b(out + i * 8, v);
+    }
+}
+
+// dgate[b,c] = sum_t (da[b,t,c] + db[b,t,c]) * x[b,t,c]; grid (ceil(C/256), B), the features before the gate in x
+__global__ void clip_gate_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ db, const bf16* __restrict__ x,
+                                            float* __restrict__ dgate, int T, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const long i = ((long)b * T + t) * C + c;
+        acc += (da[i] + (db ? db[i] : 0.f)) * bf2f(x[i]);
+    }
+    dgate[(long)b * C + c] = acc;
+}
+
+// out[b,t,c] = (da + db)[b,t,c] * gate[b,c] + dpool[b,c]   (dpool already carries the 1/T of the mean; out may be da)
+__global__ void clip_gate_bwd_apply_kernel(const float* da, const float* __restrict__ db, const float* __restrict__ gate,
+                                           const float* __restrict__ dpool, float* out, int T, int C, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C;
+        const long g = (row / T) * C + (i - row * C);
+        out[i] = (da[i] + (db ? db[i] : 0.f)) * gate[g] + dpool[g];
+    }
+}
+
 // ---------------------------------------------------------------- BN backward
 struct DySrc {
     const bf16* D; const float* mul; const float* add; FastDiv group;
@@ -518,6 +557,33 @@ extern "C" int stes_se_bwd_bnsums(const float* S, const float* gate, const float
 extern "C" int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream) {
     STES_CHECK(d && g && out && n > 0, STES_ERR_ARG, "stes_sigmoid_bwd: bad argument");
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(stes_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d, g, (bf16*)out, (long)n);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_clip_gate_fwd(const uint16_t* x, const float* gate, uint16_t* out, int B, int T, int C, void* stream) {
+    STES_CHECK(x && gate && out && B > 0 && T > 0 && C > 0 && C % 8 == 0, STES_ERR_ARG, "stes_clip_gate_fwd: bad argument");
+    const long total8 = (long)B * T * (C / 8);
+    long blocks = stes_div_up(total8, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clip_gate_fwd_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)x, gate, (bf16*)out, T, C / 8, total8);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_clip_gate_bwd(const float* da, const float* db, const uint16_t* x, const float* gate, const float* dpool,
+                                  float* dgate, float* out, int B, int T, int C, void* stream) {
+    STES_CHECK(da && B > 0 && T > 0 && C > 0, STES_ERR_ARG, "stes_clip_gate_bwd: bad argument");
+    STES_CHECK((x && dgate && !out) || (gate && dpool && out && !dgate), STES_ERR_ARG,
+               "stes_clip_gate_bwd: pass (x, dgate) for the reduction or (gate, dpool, out) for the apply pass");
+    if (dgate) {
+        hipLaunchKernelGGL(clip_gate_bwd_reduce_kernel, dim3(stes_div_up(C, 256), B), dim3(256), 0, S(stream), da, db, (const bf16*)x, dgate, T, C);
+    } else {
+        const long total = (long)B * T * C;
+        long blocks = stes_div_up(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(clip_gate_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, S(stream), da, db, gate, dpool, out, T, C, total);
+    }
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -21,7 +21,7 @@ from . import lib
 from .engine import BF, Engine
 from .model.common import MLP, BaseRGBModel, step
 from .model.min_gru import MinRNNPredictor
-from .model.modules import FCPrediction, GRUPrediction
+from .model.modules import ChannelAttention, FCPrediction, GRUPrediction
 from .model.shift import make_temporal_shift
 from .regnet import create_model
 
@@ -74,16 +74,14 @@ class E2EModel(BaseRGBModel):
             is_rgb = modality == "rgb"
             in_channels = {"flow": 2, "bw": 1, "rgb": 3}[modality]
             self.feature_arch = feature_arch
-            if use_channel_attention:
-                raise NotImplementedError("use_channel_attention is outside the hot path built here")
-            self._use_channel_attention = False
+            self._use_channel_attention = use_channel_attention
             if feature_arch.startswith("rny008"):
                 features = create_model("regnety_008", pretrained=is_rgb, in_chans=in_channels)
                 feat_dim = features.head.fc.in_features
                 features.head.fc = nn.Identity()
             else:
                 raise NotImplementedError(feature_arch)
-            self._channel_attention = nn.Identity()
+            self._channel_attention = ChannelAttention(feat_dim, reduction=8) if use_channel_attention else nn.Identity()
             self._require_clip_len = -1
             if feature_arch.endswith("_tsm"):
                 make_temporal_shift(features, clip_len, is_gsm=False)

@@ -445,7 +445,10 @@ class Engine:
             return None
         gru = sorted([it for it in named if key(it) is not None], key=key)
         rest = [it for it in named if key(it) is None]
-        main = [it for it in rest if "_pred_loc" not in it[0]] + gru
+        rest_main = [it for it in rest if "_pred_loc" not in it[0]]
+        # backbone first, whatever the registration order (the gradient buckets below are contiguous ranges)
+        main = ([it for it in rest_main if it[0].startswith("_features.")]
+                + [it for it in rest_main if not it[0].startswith("_features.")] + gru)
         loc = [it for it in rest if "_pred_loc" in it[0]]
         order = main + loc
         offs, total = {}, 0
@@ -530,6 +533,13 @@ class Engine:
                 self.min_lin.append(Linear(self, w, b))
         else:
             self.fc = Linear(self, pf._fc_out.weight, pf._fc_out.bias)
+        # channel attention over the clip (reference train_e2e_spatial.py:348-354,437-438): two bias-free linears
+        self.ca = None
+        if getattr(impl, "_use_channel_attention", False):
+            fc = impl._channel_attention.fc
+            self.ca = (Linear(self, fc[0].weight), Linear(self, fc[2].weight))
+            if self.ca[0].N % 8:
+                raise NotImplementedError("channel attention: reduced width must be a multiple of 8")
         self.loc = None
         if getattr(impl, "_predict_location", False):
             mlp, last = impl._pred_loc[0], impl._pred_loc[1]
@@ -578,10 +588,16 @@ class Engine:
         self.Hl, self.Wl = h, w
         Fd = self.feat_dim
         self.feat = a("feat", N * Fd, BF)
+        # feat_in: what the heads see (the attended features when channel attention is on)
+        self.feat_in = self.feat
+        if self.ca is not None:
+            self.feat_in = a("ca.out", N * Fd, BF)
+            self.ca_pool, self.ca_hidden = a("ca.pool", B * Fd, BF), a("ca.hidden", B * self.ca[0].N, BF)
+            self.ca_gate = a("ca.gate", B * Fd, F32)
         # heads may run on the first Th <= T frames of every clip (a zero-padded last window is un-padded before the
         # heads, reference train_e2e_spatial.py:440-442)
         self.Th, self.Nh = Th, B * Th
-        self.feat_h = self.feat if Th == T else a("feat_h", B * Th * Fd, BF)
+        self.feat_h = self.feat_in if Th == T else a("feat_h", B * Th * Fd, BF)
         N_bb, N, T = N, B * Th, Th
         if self.head_kind == "gru":
             for i, L in enumerate(self.gru_layers):
@@ -649,8 +665,16 @@ class Engine:
         HWl = self.Hl * self.Wl
         lib.call("stes_chan_pool", p(X), None, None, None, None, p(self.feat), N, HWl, self.feat_dim, 1.0 / HWl)
         self._last_out = X
+        if self.ca is not None:
+            # gate[b] = sigmoid(W2 relu(W1 mean_t feat[b,t])) over all T frames of the (padded) clip; feat_in = feat * gate
+            c1, c2 = self.ca
+            Fd = self.feat_dim
+            lib.call("stes_chan_pool", p(self.feat), None, None, None, None, p(self.ca_pool), B, T, Fd, 1.0 / T)
+            lib.gemm(self.ca_pool, c1.w_bf, self.ca_hidden, B, c1.N, Fd, act=1)
+            lib.gemm(self.ca_hidden, c2.w_bf, self.ca_gate, B, Fd, c1.N, act=2)
+            lib.call("stes_clip_gate_fwd", p(self.feat), p(self.ca_gate), p(self.feat_in), B, T, Fd)
         if self.Th != T:
-            self.feat_h.view(B, self.Th, self.feat_dim).copy_(self.feat.view(B, T, self.feat_dim)[:, :self.Th])
+            self.feat_h.view(B, self.Th, self.feat_dim).copy_(self.feat_in.view(B, T, self.feat_dim)[:, :self.Th])
         return self._heads_forward(train)
 
     def _heads_forward(self, train):
@@ -729,7 +753,7 @@ class Engine:
                 a = lib.gru_args(gi=L.gi, whh=L.whh_bf, whhT=L.whhT_bf, bhh=L.bhh_all, y=L.y, hstate=L.hstate, saved=L.saved,
                                  hprev_bf=L.hprev, dy=dy, ld_dy=2 * Hh, mask=mask, dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=Hh)
                 lib.check(lib.lib().stes_gru_backward(C.byref(a), lib.stream()), "stes_gru_backward")
-                xin = self.feat if li == 0 else self.gru_layers[li - 1].y
+                xin = self.feat_in if li == 0 else self.gru_layers[li - 1].y
                 lib.wgrad(dgi, xin, g(L.wih_all), N, 6 * Hh, L.I, dbias=g(L.bih_all))
                 gw, gb = g(L.whh_all), g(L.bhh_all)
                 dgh_v, hp_v = dgh.view(2, T * B, 3 * Hh), L.hprev.view(2, T * B, Hh)
@@ -751,7 +775,7 @@ class Engine:
                 Hh = lin.N // 2
                 dpre = sc("min.dpre", N * 2 * Hh)
                 lib.call("stes_mingru_scan_bwd", p(self.min_pre[i]), p(self.impl._pred_fine.h0[i]), p(self.min_h[i]), p(dh), Hh, p(dpre), B, T, Hh)
-                xin = self.feat if i == 0 else self.min_h[i - 1]
+                xin = self.feat_in if i == 0 else self.min_h[i - 1]
                 lib.wgrad(dpre, xin, g(lin.w), N, 2 * Hh, lin.K, dbias=g(lin.b))
                 if i == 0:
                     lib.gemm(dpre, lin.wT_bf, dfa, N, Fd, 2 * Hh, ldw=lin.Np)
@@ -759,7 +783,7 @@ class Engine:
                     dh = sc(f"min.dh{i}", N * lin.K, F32)
                     lib.gemm(dpre, lin.wT_bf, dh, N, lin.K, 2 * Hh, ldw=lin.Np)
         else:
-            lib.wgrad(dlogits_bf, self.feat, g(fc.w), N, fc.N, Fd, ldp=ncp, dbias=g(fc.b))
+            lib.wgrad(dlogits_bf, self.feat_in, g(fc.w), N, fc.N, Fd, ldp=ncp, dbias=g(fc.b))
             lib.gemm(dlogits_bf, fc.wT_bf, dfa, N, Fd, ncp, ldw=fc.Np)
         if self.loc is not None and dloc_bf is not None:
             l1, l2, l3 = self.loc
@@ -769,11 +793,25 @@ class Engine:
             lib.wgrad(dh2, self.loc_h1, g(l2.w), N, l2.N, l2.K, dbias=g(l2.b))
             dh1 = sc("loc.dh1", N * l1.N)
             lib.gemm(dh2, l2.wT_bf, dh1, N, l1.N, l2.N, ldw=l2.Np, relu_mask=self.loc_h1, ldmask=l1.N)
-            lib.wgrad(dh1, self.feat, g(l1.w), N, l1.N, Fd, dbias=g(l1.b))
+            lib.wgrad(dh1, self.feat_in, g(l1.w), N, l1.N, Fd, dbias=g(l1.b))
             dfb = sc("dfeat.b", N * Fd, F32)
             lib.gemm(dh1, l1.wT_bf, dfb, N, Fd, l1.N, ldw=l1.Np)
         if dfeat_extra is not None:
             dfa.add_(dfeat_extra.reshape(-1).float())
+        if self.ca is not None:
+            # y = x * gate(mean_t x): d gate = sum_t dy * x, through the two linears back to the mean, then
+            # dx = dy * gate + d mean / T  (written over dfa; dfb is consumed here)
+            c1, c2 = self.ca
+            dgate, dpool = sc("ca.dgate", B * Fd, F32), sc("ca.dpool", B * Fd, F32)
+            dpre2, dpre1 = sc("ca.dpre2", B * Fd), sc("ca.dpre1", B * c1.N)
+            lib.call("stes_clip_gate_bwd", p(dfa), p(dfb), p(self.feat), None, None, p(dgate), None, B, T, Fd)
+            lib.call("stes_sigmoid_bwd", p(dgate), p(self.ca_gate), p(dpre2), B * Fd)
+            lib.gemm(dpre2, c2.wT_bf, dpre1, B, c1.N, Fd, ldw=c2.Np, relu_mask=self.ca_hidden, ldmask=c1.N)
+            lib.gemm(dpre1, c1.wT_bf, dpool, B, Fd, c1.N, ldw=c1.Np, out_scale=1.0 / T)
+            lib.wgrad(dpre2, self.ca_hidden, g(c2.w), B, Fd, c1.N)
+            lib.wgrad(dpre1, self.ca_pool, g(c1.w), B, c1.N, Fd)
+            lib.call("stes_clip_gate_bwd", p(dfa), p(dfb), None, p(self.ca_gate), p(dpool), None, p(dfa), B, T, Fd)
+            dfb = None
         # --- backbone
         HWl = self.Hl * self.Wl
         dZ = self.scratch_pp("dZ", self.N * HWl * Fd)

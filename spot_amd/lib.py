@@ -75,6 +75,8 @@ _SIGS = {
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
+    "stes_clip_gate_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_clip_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_se_bwd_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_se_bwd_bnsums": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "stes_bn_bwd_reduce": [_P, _P],
@@ -154,6 +156,7 @@ def _conv_bytes(a):
 
 # entry point -> (kernel name, algorithmic bytes of one call): every operand read once, every result written once
 _KERNEL_OF = {
+    "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
     "stes_conv3x3g_fwd": ("conv3x3g_rows_kernel (forward)", _conv_bytes),
     "stes_conv3x3g_dgrad": ("conv3x3g_rows_kernel / conv3x3g_dgrad2_kernel (input gradient)",
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),

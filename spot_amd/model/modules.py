@@ -24,3 +24,14 @@ class GRUPrediction(nn.Module):
         self._dropout = nn.Dropout()
 
     forward = _no_forward
+
+
+class ChannelAttention(nn.Module):
+    """reference model/modules.py:86-105 (state-dict keys fc.0.weight [F/r, F], fc.2.weight [F, F/r])"""
+
+    def __init__(self, feat_dim, reduction=8):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(feat_dim, feat_dim // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(feat_dim // reduction, feat_dim, bias=False), nn.Sigmoid())
+
+    forward = _no_forward

@@ -52,6 +52,7 @@ def get_args(argv=None):
     p.add_argument("--criterion", choices=["map", "loss"], default="loss")
     p.add_argument("--start_val_epoch", type=int, default=30)
     p.add_argument("--time_backward", action="store_true")
+    p.add_argument("--use_channel_attention", action="store_true")
     p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
     p.add_argument("--device", type=str, default="cuda")
     return p.parse_args(argv)
@@ -209,7 +210,7 @@ def store_config(file_path, args, num_epochs, classes):
     config = {"dataset": args.dataset, "num_classes": len(classes), "modality": args.modality, "feature_arch": args.feature_arch,
               "temporal_arch": args.temporal_arch, "clip_len": args.clip_len, "batch_size": args.batch_size, "crop_dim": args.crop_dim,
               "num_epochs": num_epochs, "warm_up_epochs": args.warm_up_epochs, "learning_rate": args.learning_rate,
-              "predict_location": args.predict_location, "pred_loc_arch": args.pred_loc_arch, "time_backward": args.time_backward,
+              "predict_location": args.predict_location, "pred_loc_arch": args.pred_loc_arch, "time_backward": args.time_backward, "use_channel_attention": args.use_channel_attention,
               "acc_grad_iter": args.acc_grad_iter, "criterion": args.criterion, "start_val_epoch": args.start_val_epoch}
     with open(file_path, "w") as fp:
         json.dump(config, fp, indent=2, sort_keys=True)
@@ -228,7 +229,7 @@ def main(args):
     classes = load_classes(args)
     model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
                      device=args.device, predict_location=args.predict_location, pred_loc_arch=args.pred_loc_arch,
-                     time_backward=args.time_backward)
+                     time_backward=args.time_backward, use_channel_attention=args.use_channel_attention)
     train_loader, val_loader = get_loaders(args, len(classes) + 1)
     optimizer, scaler = model.get_optimizer({"lr": args.learning_rate})
     num_steps_per_epoch = len(train_loader) // args.acc_grad_iter

@@ -97,6 +97,107 @@ def test_deeper_gru_training_gradients_of_the_head_vs_oracle():
     print("deeper_gru head gradients, worst rel. L2 vs fp32 oracle: %.3f" % worst)
 
 
+def test_channel_attention_kernels_vs_reference_golden(golden):
+    """The engine's kernel sequence for the clip-level channel gate on the reference's own vectors (ChannelAttention,
+    model/modules.py:86-105, [3, 5, 64] features, reduction 8): output, input gradient, both weight gradients."""
+    import ctypes as C
+    from spot_amd import lib
+    z = golden("channel_attention")
+    dev, BF16 = "cuda", torch.bfloat16
+    B, T, Fd, R = 3, 5, 64, 8
+    t = lambda k, dt=torch.float32: torch.from_numpy(z[k]).to(dev).to(dt).contiguous()
+    x, w1, w2, dy = t("x", BF16), t("w1", BF16), t("w2", BF16), t("dy")
+    xq = x.float().cpu()
+    p = lib.ptr
+    pool, hid = torch.empty(B, Fd, dtype=BF16, device=dev), torch.empty(B, R, dtype=BF16, device=dev)
+    gate, y = torch.empty(B, Fd, device=dev), torch.empty(B * T, Fd, dtype=BF16, device=dev)
+    lib.call("stes_chan_pool", p(x), None, None, None, None, p(pool), B, T, Fd, 1.0 / T)
+    lib.gemm(pool, w1, hid, B, R, Fd, act=1)
+    lib.gemm(hid, w2, gate, B, Fd, R, act=2)
+    lib.call("stes_clip_gate_fwd", p(x), p(gate), p(y), B, T, Fd)
+    assert rel(y.cpu().view(B, T, Fd), z["y"]) < 1e-2
+    dgate, dpool = torch.empty(B, Fd, device=dev), torch.empty(B, Fd, device=dev)
+    dpre2, dpre1 = torch.empty(B, Fd, dtype=BF16, device=dev), torch.empty(B, R, dtype=BF16, device=dev)
+    dw1, dw2, dx = torch.zeros(R, Fd, device=dev), torch.zeros(Fd, R, device=dev), torch.empty(B * T, Fd, device=dev)
+    lib.call("stes_clip_gate_bwd", p(dy), None, p(x), None, None, p(dgate), None, B, T, Fd)
+    np.testing.assert_allclose(dgate.cpu(), (torch.from_numpy(z["dy"]) * xq).sum(1), rtol=1e-5, atol=1e-5)
+    lib.call("stes_sigmoid_bwd", p(dgate), p(gate), p(dpre2), B * Fd)
+    lib.gemm(dpre2, w2.t().contiguous(), dpre1, B, R, Fd, relu_mask=hid, ldmask=R)
+    lib.gemm(dpre1, w1.t().contiguous(), dpool, B, Fd, R, out_scale=1.0 / T)
+    lib.wgrad(dpre2, hid, dw2, B, Fd, R)
+    lib.wgrad(dpre1, pool, dw1, B, R, Fd)
+    lib.call("stes_clip_gate_bwd", p(dy), None, None, p(gate), p(dpool), None, p(dx), B, T, Fd)
+    torch.cuda.synchronize()
+    for name, got, tol in (("dx", dx.view(B, T, Fd), 1e-2), ("dw1", dw1, 2e-2), ("dw2", dw2, 2e-2)):
+        r = rel(got.cpu(), z[name])
+        print(name, r)
+        assert r < tol, (name, r)
+    with pytest.raises(lib.StesError):            # neither the reduction's nor the apply pass's argument set
+        lib.call("stes_clip_gate_bwd", p(dy), None, p(x), p(gate), p(dpool), p(dgate), p(dx), B, T, Fd)
+
+
+def test_channel_attention_forward_and_gradients_vs_oracle():
+    """--use_channel_attention (reference train_e2e_spatial.py:348-354,437-438): the per-clip channel gate between the
+    backbone and the heads.  Eval predictions (also for a padded clip: the gate averages over the padded frames), then one
+    training forward/backward against the fp32 oracle: loss, the gate MLP's two weight gradients, and the gradients on both
+    sides of it (classifier, last backbone block)."""
+    from oracle import stes_oracle as O
+    from spot_amd.e2e import E2EModel
+    om = O.Impl(7, "rny008_gsm", "gru", clip_len=4, predict_location=True, use_channel_attention=True)
+    O.randomize_(om, seed=9)
+    with torch.no_grad():                      # gates well away from 0.5 so that the attention matters
+        om._channel_attention.fc[2].weight.mul_(3.0)
+    m = E2EModel(7, "rny008_gsm", "gru", clip_len=4, modality="rgb", device="cuda", predict_location=True, verbose=False,
+                 use_channel_attention=True)
+    assert set(m._model.state_dict()) == set(om.state_dict())
+    m._model.load_state_dict(om.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(41)
+    for Tv in (4, 3):
+        x = torch.randn(2, Tv, 3, 64, 64, generator=g)
+        cls, scores, loc = m.predict(x)
+        ocls, oscores, oloc = O.predict(om, x)
+        np.testing.assert_allclose(scores, oscores, atol=2e-2)
+        np.testing.assert_allclose(loc, oloc, atol=2e-2)
+    om.eval(); m._model.eval()
+    x = torch.randn(2, 4, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        gate = torch.sigmoid(om._channel_attention.fc[2](torch.relu(om._channel_attention.fc[0](om._features(x.reshape(-1, 3, 64, 64)).reshape(2, 4, -1).mean(1)))))
+    assert float(gate.std()) > 0.05                                  # not a constant scaling
+    for mod in (om, m._model):
+        mod.train()
+        mod._pred_fine._dropout.p = 0.0
+    m._model.engine.drop_p = 0.0
+    x = torch.randn(2, 4, 3, 64, 64, generator=g)
+    label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+    od = om(x)
+    with torch.no_grad():
+        s_ = od["loc_feat"].sigmoid()
+        xy = (s_ + torch.where(torch.rand(2, 4, 2, generator=g) < 0.5, -0.2, 0.2)).clamp(0.0, 1.0)
+    ol, _, _ = O.stes_loss(od["im_feat"], od["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+    ol.backward()
+    og = {n: p.grad.clone() for n, p in om.named_parameters() if p.grad is not None}
+    # yardstick: the same oracle with the kernels' bf16 storage rounding (see test_train_forward_backward_vs_reference_and_oracle)
+    om.zero_grad()
+    O.set_storage_rounding(True)
+    try:
+        od16 = om(x)
+        l16, _, _ = O.stes_loss(od16["im_feat"], od16["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+        l16.backward()
+    finally:
+        O.set_storage_rounding(False)
+    g16 = {n: p.grad for n, p in om.named_parameters() if p.grad is not None}
+    out = m.train_step(x.cuda(), label.cuda(), xy.cuda(), lr=0.0, optimizer_step=False).cpu()
+    assert abs(float(out[0]) - float(ol.detach())) < 3e-2 * abs(float(ol.detach())), (out, ol)
+    bad = []
+    for n, p in m._model.named_parameters():
+        if n.startswith("_channel_attention") or n.startswith("_pred_fine._fc_out") or n in (
+                "_features.s4.b2.conv3.conv.weight", "_features.s4.b2.se.fc2.weight", "_pred_loc.0.layers.0.weight"):
+            r, yard = rel(p.grad.cpu(), og[n]), rel(g16[n], og[n])
+            print("%-40s ours vs fp32 %.3f   bf16-rounded oracle vs fp32 %.3f" % (n, r, yard))
+            bad += [(n, r, yard)] if r > max(0.04, 2.5 * yard) else []
+    assert not bad, bad
+
+
 def test_short_clip_is_padded_then_unpadded_like_reference():
     """T < clip_len: frames are zero-padded for the backbone and the heads run on the true length
     (reference train_e2e_spatial.py:423-442)."""

@@ -114,6 +114,22 @@ def test_mingru(golden):
             np.testing.assert_allclose(p.grad.numpy(), z["g." + n], rtol=1e-4, atol=1e-5)
 
 
+def test_channel_attention(golden):
+    """The clip-level channel gate (reference model/modules.py:86-105): output and all three gradients."""
+    z = golden("channel_attention")
+    m = O.ChannelAttention(64, reduction=8)
+    with torch.no_grad():
+        m.fc[0].weight.copy_(T(z["w1"])); m.fc[2].weight.copy_(T(z["w2"]))
+    assert set(m.state_dict()) == {"fc.0.weight", "fc.2.weight"}
+    x = T(z["x"]).clone().requires_grad_(True)
+    y = m(x)
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=1e-5, atol=1e-6)
+    y.backward(T(z["dy"]))
+    np.testing.assert_allclose(x.grad.numpy(), z["dx"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.fc[0].weight.grad.numpy(), z["dw1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.fc[2].weight.grad.numpy(), z["dw2"], rtol=1e-4, atol=1e-6)
+
+
 def test_step_loss_adamw(golden):
     z = golden("step_heads")
 

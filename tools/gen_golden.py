@@ -289,6 +289,18 @@ def gen_scores():
          tolerances=np.array(tol1), mAPs_t=np.array(mt, np.float64), mAP_ps=np.array(mp, np.float64))
 
 
+def gen_channel_attention():
+    """reference model/modules.py:86-105 on [3, 5, 64] features: output and every gradient."""
+    torch.manual_seed(17)
+    m = RM.ChannelAttention(64, reduction=8)
+    x = torch.randn(3, 5, 64, requires_grad=True)
+    dy = torch.randn(3, 5, 64)
+    y = m(x)
+    (y * dy).sum().backward()
+    save("channel_attention", x=x.detach(), dy=dy, w1=m.fc[0].weight.detach(), w2=m.fc[2].weight.detach(), y=y.detach(),
+         dx=x.grad, dw1=m.fc[0].weight.grad, dw2=m.fc[2].weight.grad)
+
+
 def gen_eval():
     """Accumulated window scores -> frame error, F1 counts, event lists, windowed peak picking (reference util/eval.py)."""
     import json
@@ -424,8 +436,10 @@ if __name__ == "__main__":
         gen_scores()
     if not only or "eval" in only:
         gen_eval()
-    if "scores" in only or "eval" in only:
-        only = [t for t in only if t not in ("scores", "eval")] or ["-"]
+    if not only or "channel_attention" in only:
+        gen_channel_attention()
+    if "scores" in only or "eval" in only or "channel_attention" in only:
+        only = [t for t in only if t not in ("scores", "eval", "channel_attention")] or ["-"]
     if not only:
         gen_gsm()
         gen_gated_shift()
