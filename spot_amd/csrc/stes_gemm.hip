@@ -10,6 +10,7 @@
 // stes_wgrad: dW[N1,N2] += P^T pro(Q); the reduction runs over the rows, so both operands are
 //             consumed transposed: tiles land in LDS row-major and are fetched with
 //             ds_read_b64_tr_b16 straight into MFMA fragment order.
+#include <cstdlib>
 #include "stes_common.h"
 
 namespace {
@@ -856,8 +857,14 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     STES_CHECK(!a->p_raw || !big, STES_ERR_UNSUPPORTED, "stes_wgrad: the P prologue exists for the 64-wide tile only (N1 <= 64 or N2 <= 64)");
     const int t = big ? 128 : 64;
     const int t1 = stes_div_up(a->N1, t), t2 = stes_div_up(a->N2, t);
-    // split the rows so that the grid has ~1024 workgroups, at least 256 rows each
-    long want = 1024 / (t1 * t2);
+    // Split the rows so that the grid has about `total` workgroups, at least 256 rows each.  The 128-tile holds two
+    // workgroups per CU (LDS), and 512 of them -- one resident set -- beat finer splits (every extra chunk adds a tile of
+    // atomics) and coarser ones (one workgroup per CU hides no latency); with one to three tiles and short chunks, or the
+    // many tiles of the head matrices, one workgroup per CU is enough.  The 64-tile is HBM-bound and likes more, smaller ones.
+    const int nt = t1 * t2;
+    long total = 1024;
+    if (big) total = (nt >= 64 || (nt <= 3 && a->M * nt <= (1L << 20))) ? 256 : 512;
+    long want = total / nt;
     if (want < 1) want = 1;
     long chunk = (a->M + want - 1) / want;
     if (chunk < 256) chunk = 256;
