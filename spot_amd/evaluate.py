@@ -60,7 +60,7 @@ class VideoClipDataset:
             if b % world == rank:
                 items = [self[i] for i in range(lo, min(lo + batch_size, len(self)))]
                 yield {"video": [x["video"] for x in items], "start": [x["start"] for x in items],
-                       "frame": torch.stack([x["frame"] for x in items])}
+                       "frame": torch.stack([x["frame"] for x in items]), "index": list(range(lo, lo + len(items)))}
 
     def get_labels(self, video, with_locations=False):
         meta = self._labels[self._video_idxs[video]]
@@ -91,8 +91,9 @@ class VideoClipDataset:
         return out
 
 
-def accumulate(model, dataset, num_classes, predict_location, batch_size=INFERENCE_BATCH_SIZE, rank=0, world=1):
-    """video -> (score sums, support, last location) over this rank's clips (train_e2e_spatial.py:668-738)."""
+def accumulate(model, dataset, num_classes, predict_location, batch_size=INFERENCE_BATCH_SIZE, rank=0, world=1, writer=None):
+    """video -> (score sums, support, last location) over this rank's clips (train_e2e_spatial.py:668-738).  `writer`
+    (video -> int array, -1 = nobody) receives the dataset index of the clip that wrote each frame's location last."""
     pred = {v: (np.zeros((n, num_classes + 1), np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32))
             for v, n, _ in dataset.videos}
     for clip in dataset.batches(batch_size, rank, world):
@@ -110,19 +111,44 @@ def accumulate(model, dataset, num_classes, predict_location, batch_size=INFEREN
             support[start:end] += 1
             if predict_location:
                 locations[start:end] = loc[: end - start]
+            if writer is not None:
+                writer[video][start:end] = clip["index"][i]
     return pred
 
 
+def accumulate_distributed(model, dataset, num_classes, predict_location, dist, batch_size=INFERENCE_BATCH_SIZE, device="cpu"):
+    """Every rank evaluates every world-th batch of clips (replicas only: clips are independent), then the accumulators are
+    summed over the ranks.  Where clips overlap, a frame's location is the one written by the clip latest in dataset order,
+    as in the reference's single loop -- whichever rank ran it."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    writer = {v: np.full(n, -1, np.int64) for v, n, _ in dataset.videos}
+    pred = accumulate(model, dataset, num_classes, predict_location, batch_size, rank, world, writer)
+    out = {}
+    for v in sorted(pred):
+        scores, support, locations = (torch.from_numpy(a).to(device) for a in pred[v])
+        w = torch.from_numpy(writer[v]).to(device)
+        last = w.clone()
+        dist.all_reduce(last, op=dist.ReduceOp.MAX)
+        locations = locations * ((w == last) & (w >= 0)).unsqueeze(1)       # each frame survives on exactly one rank
+        for t in (scores, support, locations):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out[v] = (scores.cpu().numpy(), support.cpu().numpy(), locations.cpu().numpy())
+    return out
+
+
 def evaluate(model, dataset, split, classes, save_pred=None, calc_stats=True, save_scores=True, predict_location=False,
-             px_scale=224, batch_size=INFERENCE_BATCH_SIZE, reduce=None, quiet=False):
+             px_scale=224, batch_size=INFERENCE_BATCH_SIZE, dist=None, device="cpu", quiet=False):
     """Returns the harmonic mean of the temporal mAP (tolerances 1, 2, 4) and the spatial mAP when predict_location, else
-    the mean temporal mAP over tolerances 0..5.  `reduce(pred_dict)` sums the per-rank accumulators in a multi-process
-    run (disjoint clips per rank; without overlap the location planes are disjoint too)."""
+    the mean temporal mAP over tolerances 0..5.  With `dist` (an initialised torch.distributed: "nccl" with device="cuda",
+    or "gloo") the clips are dealt over the ranks and every rank returns the same number; rank 0 writes the files."""
     if dataset.augment:
         raise NotImplementedError("flip / multi-crop test-time augmentation")
-    pred = accumulate(model, dataset, len(classes), predict_location, batch_size)
-    if reduce is not None:
-        pred = reduce(pred)
+    if dist is not None:
+        pred = accumulate_distributed(model, dataset, len(classes), predict_location, dist, batch_size, device)
+        quiet = quiet or dist.get_rank() != 0
+        save_pred = save_pred if dist.get_rank() == 0 else None
+    else:
+        pred = accumulate(model, dataset, len(classes), predict_location, batch_size)
     proc = process_frame_predictions_with_location if predict_location else process_frame_predictions
     err, f1, pred_events, pred_events_high_recall, pred_scores = proc(
         dataset, classes, pred if predict_location else {v: p[:2] for v, p in pred.items()})

@@ -249,6 +249,70 @@ def test_dp_bucketed_allreduce_and_global_denominators_gloo():
         assert den.tolist() == [32.0, 4.0]
 
 
+class _PixelModel:
+    """Scores and locations that depend on the frame's pixel value AND on the clip it sits in (its first pixel), so that
+    overlapping clips disagree about a frame, as a real model's do."""
+
+    def predict(self, clip):
+        v = clip[:, :, 0, 0, 0].float().numpy()                       # [B, T]
+        ctx = v[:, :1] * 0.01
+        scores = np.stack([np.cos(v + ctx) ** 2, np.sin(v + ctx) ** 2 * 0.7, np.sin(2 * v + ctx) ** 2 * 0.4], -1).astype(np.float32)
+        loc = np.stack([(v * 0.37 + ctx) % 1.0, (v * 0.11 + 2 * ctx) % 1.0], -1).astype(np.float32).reshape(v.shape[0], -1)
+        return scores.argmax(-1), scores, loc
+
+
+def _eval_dataset():
+    from spot_amd import evaluate as EV
+    classes = {"serve": 1, "set": 2}
+    labels = [{"video": "v0", "num_frames": 70, "fps": 25, "events": [{"frame": 9, "label": "serve", "xy": [0.2, 0.5]},
+                                                                      {"frame": 40, "label": "set", "xy": [0.7, 0.2]}]},
+              {"video": "v1", "num_frames": 33, "fps": 25, "events": [{"frame": 20, "label": "set", "xy": [0.5, 0.5]}]}]
+    frames = {l["video"]: torch.arange(1, l["num_frames"] + 1, dtype=torch.uint8).view(-1, 1, 1, 1).expand(-1, 3, 2, 2).contiguous() for l in labels}
+    return classes, EV.VideoClipDataset(classes, labels, frames, clip_len=16, overlap_len=8)
+
+
+def _eval_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spot_amd import evaluate as EV
+    classes, ds = _eval_dataset()
+    pred = EV.accumulate_distributed(_PixelModel(), ds, 2, True, dist, batch_size=2)
+    m = EV.evaluate(_PixelModel(), ds, "VAL", classes, predict_location=True, dist=dist, batch_size=2, quiet=True)
+    q.put((rank, {v: [a.copy() for a in p] for v, p in pred.items()}, float(m)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_evaluation_equals_the_single_process_loop_gloo():
+    """Clips dealt over two ranks, accumulators summed: the same scores, support and last-writer locations (clips overlap by
+    half here) as the reference's one loop over the dataset, and the same metric on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from spot_amd import evaluate as EV
+    classes, ds = _eval_dataset()
+    want = EV.accumulate(_PixelModel(), ds, 2, True, batch_size=2)
+    want_m = float(EV.evaluate(_PixelModel(), ds, "VAL", classes, predict_location=True, batch_size=2, quiet=True))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, pred, m in res:
+        assert m == want_m
+        for v in want:
+            assert np.array_equal(pred[v][1], want[v][1]) and want[v][1].max() == 2
+            np.testing.assert_allclose(pred[v][0], want[v][0], rtol=1e-6)
+            assert np.array_equal(pred[v][2], want[v][2])
+
+
 def test_train_driver_schedule_and_resume_rules(tmp_path):
     """spot_amd.train mirrors the reference's schedule (train_e2e_spatial.py:1014-1031) and resume rules (:936-981):
     `_fc_out` tensors are dropped and the rest loaded non-strictly; optimizer state is restored only on --resume and only
