@@ -14,6 +14,15 @@ on) additionally needs whole validation videos: `val.json` in the reference's la
 `val_videos/<video>.npy`, uint8 [num_frames, 3, H, W], which are memory-mapped; `synthetic` makes two random videos.
 
     python -m spot_amd.train DATASET FRAME_DIR -m rny008_gsm -t gru --clip_len 64 --batch_size 16 --predict_location -s DIR
+
+`--fused` trains through `E2EModel.train_step` (loss, backward and AdamW in HIP, no host synchronisation inside an epoch)
+instead of the reference-style `epoch()` loop; it is implied when the script runs under torchrun:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m spot_amd.train ... (same flags)
+
+Then `--batch_size` is per GPU (16 clips each, as the reference's nn.DataParallel run at 8x the batch), rank r takes every
+world-th batch, gradients are all-reduced over RCCL (spot_amd/dp.py), rank 0 writes the files.  The optimizer file keeps
+torch.optim.AdamW's format in both modes, so a run can be resumed in the other one, or by the reference.
 """
 from __future__ import annotations
 
@@ -55,6 +64,7 @@ def get_args(argv=None):
     p.add_argument("--use_channel_attention", action="store_true")
     p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
     p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--fused", action="store_true", help="HIP loss + backward + AdamW (implied under torchrun)")
     return p.parse_args(argv)
 
 
@@ -63,21 +73,27 @@ class ClipShards:
     """Batches in the format the reference's loaders hand to `E2EModel.epoch` (train_e2e_spatial.py:537-547): a dict with
     `frame`, `label`, `xy`.  Frames stay uint8 until the stem kernel."""
 
-    def __init__(self, files, batch_size):
-        self.files, self.batch_size = sorted(files), batch_size
+    def __init__(self, files, batch_size, rank=0, world=1):
+        self.files, self.batch_size, self.rank, self.world = sorted(files), batch_size, rank, world
         self._n = []
         for f in self.files:
             with np.load(f) as z:
                 self._n.append(int(z["label"].shape[0]))
 
     def __len__(self):
-        return sum(n // self.batch_size for n in self._n)
+        return sum(n // self.batch_size for n in self._n) // self.world      # every rank the same number of steps
 
     def __iter__(self):
+        b, todo = 0, len(self) * self.world
         for f in self.files:
             with np.load(f) as z:
                 frame, label, xy = z["frame"], z["label"], z["xy"]
             for i in range(0, label.shape[0] - self.batch_size + 1, self.batch_size):
+                b += 1
+                if b > todo:
+                    return
+                if (b - 1) % self.world != self.rank:
+                    continue
                 s = slice(i, i + self.batch_size)
                 yield {"frame": torch.from_numpy(frame[s]), "label": torch.from_numpy(label[s]).long(),
                        "xy": torch.from_numpy(xy[s]).float()}
@@ -101,16 +117,16 @@ class SyntheticClips:
                    "xy": torch.rand(self.bs, self.T, 2, generator=g)}
 
 
-def get_loaders(args, num_classes):
+def get_loaders(args, num_classes, rank=0, world=1):
     bs = args.batch_size // args.acc_grad_iter
     if args.frame_dir.startswith("synthetic"):
         n = int(args.frame_dir.split(":")[1]) if ":" in args.frame_dir else 4 * args.batch_size
         mk = lambda seed, k: SyntheticClips(k, bs, args.clip_len, args.crop_dim, num_classes, seed)
-        return mk(0, n), mk(1, max(bs, n // 4))
+        return mk(2 * rank, n), mk(2 * rank + 1, max(bs, n // 4))
     tr, va = (glob.glob(os.path.join(args.frame_dir, f"{s}_*.npz")) for s in ("train", "val"))
     if not tr or not va:
         raise FileNotFoundError(f"no train_*.npz / val_*.npz shards in {args.frame_dir}")
-    return ClipShards(tr, bs), ClipShards(va, bs)
+    return ClipShards(tr, bs, rank, world), ClipShards(va, bs, rank, world)
 
 
 def get_val_videos(args, classes):
@@ -222,15 +238,72 @@ def clear_files(dir_name, re_str):
             os.remove(os.path.join(dir_name, name))
 
 
+# ------------------------------------------------------------------------------------------- fused step <-> torch AdamW
+def export_adamw_state(model, optimizer):
+    """The engine's flat AdamW moments as torch.optim.AdamW per-parameter state (what `optim_NNN.pt` holds)."""
+    eng = model._model.engine
+    if eng.adam_m is None:
+        return
+    for p in model._model.parameters():
+        if id(p) in eng._goff:
+            o, n, shape = eng._goff[id(p)]
+            optimizer.state[p] = {"step": torch.tensor(float(eng.step_count)), "exp_avg": eng.adam_m[o:o + n].view(shape).clone(),
+                                  "exp_avg_sq": eng.adam_v[o:o + n].view(shape).clone()}
+
+
+def import_adamw_state(model, optimizer):
+    """The reverse: moments and step count of a loaded torch AdamW state into the engine's flat buffers."""
+    eng = model._model.engine
+    steps = [int(st["step"]) for st in optimizer.state.values() if "step" in st]
+    if not steps:
+        return
+    eng.adam_m, eng.adam_v = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+    eng.step_count = max(steps)
+    for p, st in optimizer.state.items():
+        if id(p) in eng._goff and "exp_avg" in st:
+            o, n, shape = eng._goff[id(p)]
+            eng.adam_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            eng.adam_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+
+
+def fused_epoch(trainer, loader, lr_scheduler, device):
+    """One training epoch through the fused step; the loss is read back once, at the end.  Returns the reference's dict."""
+    import warnings
+    total = torch.zeros(3, device=device)
+    for batch in loader:
+        trainer.lr = lr_scheduler.get_last_lr()[0]
+        out = trainer.step(batch["frame"].to(device, non_blocking=True), batch["label"].to(device), batch["xy"].to(device))
+        total += out[:3]
+        with warnings.catch_warnings():           # the torch optimizer only carries the schedule here; it never steps
+            warnings.simplefilter("ignore", UserWarning)
+            lr_scheduler.step()
+    s, c, l = (total / max(1, len(loader))).tolist()
+    return {"sum": s, "cls": c, "loc": l, "contrast": 0.0}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main(args):
     from .e2e import E2EModel
     assert args.batch_size % args.acc_grad_iter == 0
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ       # under torchrun, whatever the number of ranks
+    fused = args.fused or launched
+    dist = None
+    if launched:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        args.device = f"cuda:{local}"
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if fused and args.acc_grad_iter != 1:
+        raise NotImplementedError("--fused takes the whole per-GPU batch in one step (acc_grad_iter 1)")
+    if fused and not args.predict_location:
+        raise NotImplementedError("--fused is the path with the location head (--predict_location)")
     classes = load_classes(args)
     model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
                      device=args.device, predict_location=args.predict_location, pred_loc_arch=args.pred_loc_arch,
-                     time_backward=args.time_backward, use_channel_attention=args.use_channel_attention)
-    train_loader, val_loader = get_loaders(args, len(classes) + 1)
+                     time_backward=args.time_backward, use_channel_attention=args.use_channel_attention, verbose=rank == 0)
+    train_loader, val_loader = get_loaders(args, len(classes) + 1, rank, world)
     optimizer, scaler = model.get_optimizer({"lr": args.learning_rate})
     num_steps_per_epoch = len(train_loader) // args.acc_grad_iter
     num_epochs, lr_scheduler = get_lr_scheduler(args, optimizer, num_steps_per_epoch)
@@ -240,36 +313,62 @@ def main(args):
     if args.resume:
         epoch, losses, best_epoch, best_criterion = load_from_save(args, model, optimizer, scaler, lr_scheduler)
         epoch += 1
-    os.makedirs(args.save_dir, exist_ok=True)
+    trainer = None
+    if fused:
+        from .dp import DataParallelTrainer
+        trainer = DataParallelTrainer(model, dist, lr=args.learning_rate)       # broadcasts rank 0's weights
+        import_adamw_state(model, optimizer)
+    if rank == 0:
+        os.makedirs(args.save_dir, exist_ok=True)
     for epoch in range(epoch, num_epochs):
-        train_loss = model.epoch(train_loader, optimizer, scaler, lr_scheduler=lr_scheduler, acc_grad_iter=args.acc_grad_iter)
+        if fused:
+            train_loss = fused_epoch(trainer, train_loader, lr_scheduler, args.device)
+        else:
+            train_loss = model.epoch(train_loader, optimizer, scaler, lr_scheduler=lr_scheduler, acc_grad_iter=args.acc_grad_iter)
         val_loss = model.epoch(val_loader, acc_grad_iter=args.acc_grad_iter)
-        print("Epoch {}: train cls {:.5f} loc {:.5f} sum {:.5f} | val cls {:.5f} loc {:.5f} sum {:.5f}".format(
-            epoch, train_loss["cls"], train_loss["loc"], train_loss["sum"], val_loss["cls"], val_loss["loc"], val_loss["sum"]))
+        if dist is not None:                                 # every rank saw its own shard: average the reported losses
+            t = torch.tensor([train_loss[k] for k in ("sum", "cls", "loc")] + [val_loss[k] for k in ("sum", "cls", "loc")],
+                             device=args.device, dtype=torch.float64)
+            dist.all_reduce(t)
+            t = (t / world).tolist()
+            train_loss.update(zip(("sum", "cls", "loc"), t[:3])); val_loss.update(zip(("sum", "cls", "loc"), t[3:]))
+        if rank == 0:
+            print("Epoch {}: train cls {:.5f} loc {:.5f} sum {:.5f} | val cls {:.5f} loc {:.5f} sum {:.5f}".format(
+                epoch, train_loss["cls"], train_loss["loc"], train_loss["sum"], val_loss["cls"], val_loss["loc"], val_loss["sum"]))
         val_mAP = 0
         if args.criterion == "loss":
             if val_loss["sum"] < best_criterion:
                 best_criterion, best_epoch = val_loss["sum"], epoch
-                print("New best epoch!")
+                if rank == 0:
+                    print("New best epoch!")
         elif epoch >= args.start_val_epoch:                  # reference train_e2e_spatial.py:1158-1178
             from .evaluate import evaluate
             val_mAP = float(evaluate(model, val_videos, "VAL", classes, os.path.join(args.save_dir, "pred-val.{}".format(epoch)),
-                                     save_scores=False, predict_location=args.predict_location))
+                                     save_scores=False, predict_location=args.predict_location, dist=dist, device=args.device))
             if val_mAP > best_criterion:
                 best_criterion, best_epoch = val_mAP, epoch
-                print("New best epoch!")
+                if rank == 0:
+                    print("New best epoch!")
         losses.append({"epoch": epoch, "train": train_loss["sum"], "val": val_loss["sum"], "val_mAP": val_mAP})
-        with open(os.path.join(args.save_dir, "loss.json"), "w") as fp:
-            json.dump(losses, fp, indent=2, sort_keys=True)
-        torch.save(model.state_dict(), os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(epoch)))
-        clear_files(args.save_dir, r"optim_\d+\.pt")
-        torch.save({"optimizer_state_dict": optimizer.state_dict(),
-                    "scaler_state_dict": scaler.state_dict() if scaler is not None else {},
-                    "lr_state_dict": lr_scheduler.state_dict()}, os.path.join(args.save_dir, "optim_{:03d}.pt".format(epoch)))
-        store_config(os.path.join(args.save_dir, "config.json"), args, num_epochs, classes)
-    print("Best epoch: {}\n".format(best_epoch))
+        if rank == 0:
+            with open(os.path.join(args.save_dir, "loss.json"), "w") as fp:
+                json.dump(losses, fp, indent=2, sort_keys=True)
+            torch.save(model.state_dict(), os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(epoch)))
+            clear_files(args.save_dir, r"optim_\d+\.pt")
+            if fused:
+                export_adamw_state(model, optimizer)
+            torch.save({"optimizer_state_dict": optimizer.state_dict(),
+                        "scaler_state_dict": scaler.state_dict() if scaler is not None else {},
+                        "lr_state_dict": lr_scheduler.state_dict()}, os.path.join(args.save_dir, "optim_{:03d}.pt".format(epoch)))
+            store_config(os.path.join(args.save_dir, "config.json"), args, num_epochs, classes)
+        if dist is not None:
+            dist.barrier()
+    if rank == 0:
+        print("Best epoch: {}\n".format(best_epoch))
     if best_epoch is not None:
         model.load(torch.load(os.path.join(args.save_dir, "checkpoint_{:03d}.pt".format(best_epoch)), map_location="cpu", weights_only=True))
+    if dist is not None:
+        dist.destroy_process_group()
     return model, losses, best_epoch
 
 

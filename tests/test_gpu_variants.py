@@ -408,3 +408,62 @@ def test_train_driver_selects_the_best_epoch_by_validation_map(tmp_path):
         assert np.allclose(a[v][0], b[v][0], atol=2e-3) and np.allclose(a[v][2], b[v][2], atol=2e-3)
     m1 = EV.evaluate(model, mem, "VAL", classes, predict_location=True, quiet=True)
     assert abs(m1 - losses[1]["val_mAP"]) < 1e-9                  # the best epoch's weights were restored
+
+
+def test_train_driver_fused_mode_and_cross_mode_resume(tmp_path):
+    """--fused: epochs through the HIP loss/backward/AdamW step with the learning rate of the reference's schedule; the
+    optimizer file keeps torch.optim.AdamW's format (moments and step count per parameter), so the run resumes through the
+    reference-style loop, and a reference-style run resumes fused.  (With the minGRU head: a checkpoint that holds `_fc_out`
+    tensors -- any GRU head -- makes the reference, and this driver, skip the optimizer state on resume.)"""
+    import os
+    from spot_amd import train as TR
+    base = ["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "mingru", "--clip_len", "4", "--crop_dim", "64", "--batch_size", "2",
+            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6"]
+    model, losses, _ = TR.main(TR.get_args(base + ["--num_epochs", "2", "--fused"]))
+    assert [l["epoch"] for l in losses] == [0, 1] and all(np.isfinite(l["train"]) and np.isfinite(l["val"]) for l in losses)
+    opt = torch.load(tmp_path / "optim_001.pt", weights_only=True)
+    st = opt["optimizer_state_dict"]["state"]
+    n_trainable = sum(p.requires_grad for p in model._model.parameters())
+    assert len(st) == n_trainable and all(int(s["step"]) == 8 for s in st.values())          # 2 epochs x 4 steps
+    eng = model._model.engine
+    names = [n for n, _ in model._model.named_parameters()]
+    i = names.index("_features.s2.b1.conv1.net.conv.weight")
+    p = dict(model._model.named_parameters())[names[i]]
+    o, n, shape = eng._goff[id(p)]
+    assert torch.equal(st[i]["exp_avg"].cuda(), eng.adam_m[o:o + n].view(shape)) and float(st[i]["exp_avg_sq"].abs().sum()) > 0
+    assert opt["lr_state_dict"]["_schedulers"][0]["last_epoch"] == 8
+    sd1 = torch.load(tmp_path / "checkpoint_001.pt", weights_only=True)
+    # resume through the reference-style loop (torch AdamW picks the moments up) ...
+    model2, losses2, _ = TR.main(TR.get_args(base + ["--num_epochs", "3", "--resume"]))
+    assert [l["epoch"] for l in losses2] == [0, 1, 2] and np.isfinite(losses2[2]["train"])
+    st2 = torch.load(tmp_path / "optim_002.pt", weights_only=True)["optimizer_state_dict"]["state"]
+    assert int(st2[i]["step"]) == 12
+    # ... and again fused
+    model3, losses3, _ = TR.main(TR.get_args(base + ["--num_epochs", "4", "--resume", "--fused"]))
+    assert [l["epoch"] for l in losses3] == [0, 1, 2, 3] and model3._model.engine.step_count == 16
+    k = "_features.s1.b1.conv2.conv.weight"
+    moved = (model3.state_dict()[k].cpu() - sd1[k].cpu()).abs().max()
+    assert 0 < float(moved) < 0.05, moved
+    with pytest.raises(NotImplementedError):
+        TR.main(TR.get_args(base + ["--num_epochs", "1", "--fused", "-ag", "2"]))
+
+
+def test_train_driver_under_a_launcher_env_uses_rccl_paths(tmp_path, monkeypatch):
+    """The torchrun code path on one rank (this box has one GPU): process group over RCCL, weight broadcast, global loss
+    denominators, bucketed gradient all-reduce, loss averaging, distributed whole-video evaluation, barriers."""
+    import json
+    import socket
+    from spot_amd import train as TR
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
+        monkeypatch.setenv(k, v)
+    args = TR.get_args(["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "gru", "--clip_len", "8", "--crop_dim", "64", "--batch_size", "2",
+                        "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6",
+                        "--criterion", "map", "--start_val_epoch", "0", "--num_epochs", "2"])
+    model, losses, best = TR.main(args)
+    assert not torch.distributed.is_initialized()
+    assert len(losses) == 2 and all(np.isfinite(l["train"]) and 0 <= l["val_mAP"] <= 1 for l in losses) and best in (0, 1)
+    assert json.load(open(tmp_path / "loss.json"))[1]["val_mAP"] == losses[1]["val_mAP"]
+    assert (tmp_path / "pred-val.1.json").exists() and (tmp_path / "optim_001.pt").exists()
