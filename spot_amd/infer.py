@@ -32,7 +32,8 @@ def window_batches(n_frames, clip_len, batch_size, rank=0, world=1):
 
 def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=True, rank=0, world=1, video="video",
                   gather=None):
-    """model: E2EModel; frames [n_frames, C, H, W] float tensor (host or device).  Returns the reference's
+    """model: E2EModel; frames [n_frames, C, H, W]: float tensor (normalised; host or device), uint8 tensor (decoded), or a
+    numpy array / memory map of either.  Returns the reference's
     [{'video', 'events'}] list (after score filter 0.15 and NMS 3 when postprocess)."""
     n_frames = frames.shape[0]
     acc = ScoreAccumulator(n_frames, len(classes) + 1)
@@ -40,6 +41,8 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
         clips = []
         for s in starts:
             clip = frames[s:s + clip_len]
+            if not torch.is_tensor(clip):          # a numpy array or read-only memory map: copy the window
+                clip = torch.from_numpy(np.array(clip))
             if clip.shape[0] < clip_len:       # zero-pad the last window
                 pad = torch.zeros((clip_len - clip.shape[0],) + tuple(clip.shape[1:]), dtype=clip.dtype, device=clip.device)
                 clip = torch.cat([clip, pad], 0)
@@ -57,3 +60,53 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
         pred_events = filter_events_by_score(pred_events, fg_threshold=0.15)
         pred_events = non_max_suppression_events(pred_events, 3)
     return pred_events, scores
+
+
+def main(argv=None):
+    """Counterpart of the reference's `python inference_on_mp4.py --video_path V --checkpoint_path C --save_dir D
+    --batch_size 16 --clip_len 64` (:495-552) for a video that is already decoded and resized: `--frames` is a .npy file
+    [n_frames, 3, H, W], uint8 (normalised on the GPU) or float32 (already normalised).  The architecture comes from the
+    `config.json` beside the checkpoint when there is one (what the training driver writes), else from the flags, whose
+    defaults are the reference's (`get_args`, :27-48).  Writes D/predictions.json like the reference."""
+    import argparse
+    import json
+    import os
+    p = argparse.ArgumentParser()
+    p.add_argument("--frames", type=str, required=True)
+    p.add_argument("--checkpoint_path", type=str, required=True)
+    p.add_argument("--save_dir", type=str, default="exp/demo1")
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--clip_len", type=int, default=64)
+    p.add_argument("--feature_arch", type=str, default="rny008_gsm")
+    p.add_argument("--temporal_arch", type=str, default="gru")
+    p.add_argument("--classes", type=str, default="block dig net pass receive score serve set spike")
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--no_postprocess", action="store_true")
+    args = p.parse_args(argv)
+    from .e2e import E2EModel
+    classes = args.classes.split()
+    kw = {"feature_arch": args.feature_arch, "temporal_arch": args.temporal_arch, "predict_location": True}
+    cfg_path = os.path.join(os.path.dirname(os.path.abspath(args.checkpoint_path)), "config.json")
+    if os.path.exists(cfg_path):
+        with open(cfg_path) as fp:
+            cfg = json.load(fp)
+        kw = {k: cfg.get(k, v) for k, v in kw.items()}
+        for k in ("time_backward", "use_channel_attention"):
+            kw[k] = bool(cfg.get(k, False))
+        if cfg.get("num_classes") and cfg["num_classes"] != len(classes):
+            classes = [f"class{i + 1}" for i in range(cfg["num_classes"])]
+    model = E2EModel(len(classes) + 1, kw.pop("feature_arch"), kw.pop("temporal_arch"), clip_len=args.clip_len, modality="rgb",
+                     device=args.device, verbose=False, **kw)
+    model.load(torch.load(os.path.abspath(args.checkpoint_path), map_location="cpu", weights_only=True))
+    frames = np.load(args.frames, mmap_mode="r")
+    pred_events, _ = run_inference(model, frames, classes, args.clip_len, args.batch_size, postprocess=not args.no_postprocess,
+                                   video=os.path.basename(args.frames))
+    os.makedirs(args.save_dir, exist_ok=True)
+    with open(os.path.join(args.save_dir, "predictions.json"), "w") as fp:
+        json.dump(pred_events, fp)
+    print("{} events -> {}".format(len(pred_events[0]["events"]), os.path.join(args.save_dir, "predictions.json")))
+    return pred_events
+
+
+if __name__ == "__main__":
+    main()

@@ -467,3 +467,23 @@ def test_train_driver_under_a_launcher_env_uses_rccl_paths(tmp_path, monkeypatch
     assert len(losses) == 2 and all(np.isfinite(l["train"]) and 0 <= l["val_mAP"] <= 1 for l in losses) and best in (0, 1)
     assert json.load(open(tmp_path / "loss.json"))[1]["val_mAP"] == losses[1]["val_mAP"]
     assert (tmp_path / "pred-val.1.json").exists() and (tmp_path / "optim_001.pt").exists()
+
+
+def test_inference_cli_on_predecoded_frames_reads_the_training_drivers_files(tmp_path):
+    """python -m spot_amd.infer (the reference's inference_on_mp4.py entry point on decoded frames): architecture from the
+    config.json the training driver wrote, weights from its checkpoint, 21 uint8 frames = 3 windows of 8 with a padded
+    last one; the events equal run_inference on the same model."""
+    import json
+    from spot_amd import infer, train as TR
+    model, _, _ = TR.main(TR.get_args(["ds", "synthetic:4", "-m", "rny008_gsm", "-t", "deeper_gru", "--clip_len", "8", "--crop_dim", "64",
+                                       "--batch_size", "2", "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s",
+                                       str(tmp_path / "run"), "--num_classes", "9", "--num_epochs", "2", "--time_backward"]))
+    frames = torch.randint(0, 256, (21, 3, 64, 64), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    np.save(tmp_path / "v.npy", frames.numpy())
+    ev = infer.main(["--frames", str(tmp_path / "v.npy"), "--checkpoint_path", str(tmp_path / "run" / "checkpoint_001.pt"),
+                     "--save_dir", str(tmp_path / "out"), "--batch_size", "2", "--clip_len", "8", "--no_postprocess"])
+    assert json.load(open(tmp_path / "out" / "predictions.json")) == ev
+    want, scores = infer.run_inference(model, frames, "block dig net pass receive score serve set spike".split(), 8, batch_size=4,
+                                       postprocess=False, video="v.npy")
+    assert scores.shape == (21, 10) and [(e["frame"], e["label"]) for e in ev[0]["events"]] == [(e["frame"], e["label"]) for e in want[0]["events"]]
+    assert all(abs(a["score"] - b["score"]) < 2e-3 for a, b in zip(ev[0]["events"], want[0]["events"]))
