@@ -208,6 +208,34 @@ def test_roofline_accounting_matches_the_layer_table():
     assert 55e6 < w["step_bytes"] < 65e6                        # ~60 MB / frame fwd+bwd
 
 
+def _spawn_gloo(worker, world=2, attempts=3):
+    """Run `worker(rank, world, port, queue)` in `world` processes; a rendezvous that fails (the free port found here can
+    be taken before the ranks bind it) is tried again on another port."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for attempt in range(attempts):
+        q = ctx.Queue()
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            res = [q.get(timeout=120) for _ in range(world)]
+        except Exception:                       # noqa: BLE001 -- a rank died before reporting
+            pass
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if len(res) == world and all(p.exitcode == 0 for p in procs):
+            return res
+    raise AssertionError("gloo ranks failed %d times" % attempts)
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -228,20 +256,7 @@ def _dp_worker(rank, world, port, q):
 
 
 def test_dp_bucketed_allreduce_and_global_denominators_gloo():
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    import socket
-    with socket.socket() as sk:              # a port nobody holds right now
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _spawn_gloo(_dp_worker)
     want = torch.arange(1000, dtype=torch.float32) * 3
     for rank, flat, den in res:
         assert torch.equal(flat, want)
@@ -287,24 +302,11 @@ def _eval_worker(rank, world, port, q):
 def test_distributed_evaluation_equals_the_single_process_loop_gloo():
     """Clips dealt over two ranks, accumulators summed: the same scores, support and last-writer locations (clips overlap by
     half here) as the reference's one loop over the dataset, and the same metric on both ranks."""
-    import socket
-    import torch.multiprocessing as mp
     from spot_amd import evaluate as EV
     classes, ds = _eval_dataset()
     want = EV.accumulate(_PixelModel(), ds, 2, True, batch_size=2)
     want_m = float(EV.evaluate(_PixelModel(), ds, "VAL", classes, predict_location=True, batch_size=2, quiet=True))
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _spawn_gloo(_eval_worker)
     for rank, pred, m in res:
         assert m == want_m
         for v in want:
