@@ -266,13 +266,14 @@ def import_adamw_state(model, optimizer):
             eng.adam_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
 
 
-def fused_epoch(trainer, loader, lr_scheduler, device):
+def fused_epoch(trainer, loader, lr_scheduler, device, with_xy=True):
     """One training epoch through the fused step; the loss is read back once, at the end.  Returns the reference's dict."""
     import warnings
     total = torch.zeros(3, device=device)
     for batch in loader:
         trainer.lr = lr_scheduler.get_last_lr()[0]
-        out = trainer.step(batch["frame"].to(device, non_blocking=True), batch["label"].to(device), batch["xy"].to(device))
+        out = trainer.step(batch["frame"].to(device, non_blocking=True), batch["label"].to(device),
+                           batch["xy"].to(device) if with_xy else None)
         total += out[:3]
         with warnings.catch_warnings():           # the torch optimizer only carries the schedule here; it never steps
             warnings.simplefilter("ignore", UserWarning)
@@ -297,8 +298,6 @@ def main(args):
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if fused and args.acc_grad_iter != 1:
         raise NotImplementedError("--fused takes the whole per-GPU batch in one step (acc_grad_iter 1)")
-    if fused and not args.predict_location:
-        raise NotImplementedError("--fused is the path with the location head (--predict_location)")
     classes = load_classes(args)
     model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
                      device=args.device, predict_location=args.predict_location, pred_loc_arch=args.pred_loc_arch,
@@ -322,7 +321,7 @@ def main(args):
         os.makedirs(args.save_dir, exist_ok=True)
     for epoch in range(epoch, num_epochs):
         if fused:
-            train_loss = fused_epoch(trainer, train_loader, lr_scheduler, args.device)
+            train_loss = fused_epoch(trainer, train_loader, lr_scheduler, args.device, args.predict_location)
         else:
             train_loss = model.epoch(train_loader, optimizer, scaler, lr_scheduler=lr_scheduler, acc_grad_iter=args.acc_grad_iter)
         val_loss = model.epoch(val_loader, acc_grad_iter=args.acc_grad_iter)

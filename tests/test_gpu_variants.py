@@ -446,6 +446,13 @@ def test_train_driver_fused_mode_and_cross_mode_resume(tmp_path):
     assert 0 < float(moved) < 0.05, moved
     with pytest.raises(NotImplementedError):
         TR.main(TR.get_args(base + ["--num_epochs", "1", "--fused", "-ag", "2"]))
+    # no location head, plain backbone, frame-wise classifier: the fused step takes no xy
+    nl = [a for a in base if a != "--predict_location"]
+    nl[nl.index("rny008_gsm")] = "rny008"
+    nl[nl.index("mingru")] = ""
+    nl[nl.index(str(tmp_path))] = str(tmp_path / "noloc")
+    _, losses4, _ = TR.main(TR.get_args(nl + ["--num_epochs", "2", "--fused"]))
+    assert len(losses4) == 2 and np.isfinite(losses4[1]["train"]) and losses4[1]["train"] > 0
 
 
 def test_train_driver_under_a_launcher_env_uses_rccl_paths(tmp_path, monkeypatch):
@@ -487,3 +494,44 @@ def test_inference_cli_on_predecoded_frames_reads_the_training_drivers_files(tmp
                                        postprocess=False, video="v.npy")
     assert scores.shape == (21, 10) and [(e["frame"], e["label"]) for e in ev[0]["events"]] == [(e["frame"], e["label"]) for e in want[0]["events"]]
     assert all(abs(a["score"] - b["score"]) < 2e-3 for a, b in zip(ev[0]["events"], want[0]["events"]))
+
+
+@pytest.mark.parametrize("loc", [False, True])
+def test_plain_backbone_with_framewise_fc_head_vs_oracle(loc):
+    """-m rny008 -t "" (no temporal shift, per-frame linear classifier: reference train_e2e_spatial.py:394-395), with and
+    without the location head: clips of any length up to... any length (nothing in the model depends on clip_len), eval
+    predictions and one training step's loss and head gradients against the fp32 oracle."""
+    from oracle import stes_oracle as O
+    from spot_amd.e2e import E2EModel
+    om = O.Impl(7, "rny008", "", clip_len=4, predict_location=loc)
+    O.randomize_(om, seed=13)
+    m = E2EModel(7, "rny008", "", clip_len=4, modality="rgb", device="cuda", predict_location=loc, verbose=False)
+    assert set(m._model.state_dict()) == set(om.state_dict())
+    m._model.load_state_dict(om.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(14)
+    for Tv in (4, 6):
+        x = torch.randn(2, Tv, 3, 64, 64, generator=g)
+        out, oout = m.predict(x), O.predict(om, x)
+        assert len(out) == (3 if loc else 2)
+        np.testing.assert_allclose(out[1], oout[1], atol=2e-2)
+        if loc:
+            np.testing.assert_allclose(out[2], oout[2], atol=2e-2)
+    om.train(); m._model.train()
+    x = torch.randn(2, 4, 3, 64, 64, generator=g)
+    label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+    od = om(x)
+    xy = None
+    if loc:
+        with torch.no_grad():
+            xy = (od["loc_feat"].sigmoid() + torch.where(torch.rand(2, 4, 2, generator=g) < 0.5, -0.2, 0.2)).clamp(0.0, 1.0)
+        ol, _, _ = O.stes_loss(od["im_feat"], od["loc_feat"], label.flatten(), xy.reshape(-1, 2), 7)
+    else:
+        import torch.nn.functional as F
+        ol = F.cross_entropy(od["im_feat"].reshape(-1, 7), label.flatten(), weight=torch.tensor([1.0] + [5.0] * 6))
+    ol.backward()
+    out = m.train_step(x.cuda(), label.cuda(), xy.cuda() if loc else None, lr=0.0, optimizer_step=False).cpu()
+    assert abs(float(out[0]) - float(ol.detach())) < 3e-2 * abs(float(ol.detach())), (out, ol)
+    for n, p in m._model.named_parameters():
+        if n.startswith("_pred_fine"):
+            r = rel(p.grad.cpu(), dict(om.named_parameters())[n].grad)
+            assert r < 0.05, (n, r)
