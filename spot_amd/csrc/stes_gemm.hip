@@ -831,7 +831,9 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     STES_CHECK(!bnb, STES_ERR_UNSUPPORTED, "stes_gemm: the BatchNorm-backward prologue exists for the streaming shapes only "
                                            "(N in {32,64,128,160,320} or a multiple of 128 up to 1024, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
     const int m_tiles = stes_div_up(a->M, BM);
-    const bool wide = a->N > 64;
+    // fewer than 300 128-wide tiles (the head and squeeze-excite matrices: 1,024 rows) leave CUs idle: 64-wide tiles double
+    // the workgroups (measured 20-30 % faster on those shapes)
+    const bool wide = a->N > 64 && (long)m_tiles * stes_div_up(a->N, 128) >= 300;
     const int bn = wide ? 128 : 64;
     const int n_tiles = stes_div_up(a->N, bn);
     int m_slots = m_tiles;
