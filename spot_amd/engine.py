@@ -244,8 +244,10 @@ class Block:
         lib.call("stes_sigmoid_bwd", p(dgate), p(self.segate), p(dpre2), self.N * cmid)
         lib.gemm(dpre2, self.se2.wT_bf, dpre1, self.N, rd, cmid, ldw=self.se2.Np, relu_mask=self.hidden, ldmask=rd)
         lib.gemm(dpre1, self.se1.wT_bf, dpool, self.N, cmid, rd, ldw=self.se1.Np, out_scale=1.0 / HWo)
-        lib.wgrad(dpre2, self.hidden, g(se.fc2.weight), self.N, cmid, rd, dbias=g(se.fc2.bias))
-        lib.wgrad(dpre1, self.pooled, g(se.fc1.weight), self.N, rd, cmid, dbias=g(se.fc1.bias))
+        def se_wgrads():
+            lib.wgrad(dpre2, self.hidden, g(se.fc2.weight), self.N, cmid, rd, dbias=g(se.fc2.bias))
+            lib.wgrad(dpre1, self.pooled, g(se.fc1.weight), self.N, rd, cmid, dbias=g(se.fc1.bias))
+        side(se_wgrads)
         # --- conv2.bn backward: dY2 = (dA3*gate + dpool) * [bn2(c2) > 0]
         kw2 = dict(mul=self.segate, add=dpool, group=HWo, act=(self.c2, bn2.scale, bn2.shift))
         lib.call("stes_se_bwd_bnsums", p(S4), p(self.segate), p(dpool), p(bn2.s_dy), p(bn2.s_dyr), self.N, cmid)
