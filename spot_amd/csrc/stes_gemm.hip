@@ -529,6 +529,92 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     }
 }
 
+// ------------------------------------------------------------------ small GEMM (squeeze-excite and classifier matrices)
+// A few thousand rows at most and no operand prologue: the product is a few microseconds of latency, not bandwidth.  A
+// workgroup owns 16 rows x 64 columns; its four waves split K and read both operands straight from global memory in MFMA
+// operand layout (all loads of a pass in flight together), partial sums meet in LDS, wave 0 runs the epilogue.
+__global__ __launch_bounds__(256) void gemm_small_kernel(const stes_gemm_args p) {
+    constexpr int NI = 4, U = 4;
+    __shared__ float red[3][64][NI * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long M = p.M;
+    const int N = p.N, K = p.K;
+    const long m0 = (long)blockIdx.x * 16;
+    const int n0 = blockIdx.y * 16 * NI;
+    const bf16* __restrict__ arow = (m0 + fr < M) ? (const bf16*)p.A + (m0 + fr) * p.lda : nullptr;
+    const bf16* __restrict__ wrow[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wrow[i] = (n0 + i * 16 + fr < N) ? (const bf16*)p.W + (long)(n0 + i * 16 + fr) * p.ldw : nullptr;
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (K + 31) / 32;
+    for (int ks0 = wave; ks0 < nk; ks0 += 4 * U) {
+        bf16x8 fa[U], fb[U][NI];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (ks0 + 4 * u) * 32 + fq * 8;
+            const bool on = k < K;                       // K is a multiple of 8: a chunk is inside or outside as a whole
+            fa[u] = (on && arow) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fb[u][i] = (on && wrow[i]) ? *reinterpret_cast<const bf16x8*>(wrow[i] + k) : zero8();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u][i], fa[u], acc[i], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][lane][i * 4 + r] = acc[i][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // lane holds columns n = n0 + i*16 + fq*4 + r of row m = m0 + fr
+    const long m = m0 + fr;
+    if (m >= M) return;
+    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int nb = n0 + i * 16 + fq * 4;
+        if (nb >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = (acc[i][r] + red[0][lane][i * 4 + r] + red[1][lane][i * 4 + r] + red[2][lane][i * 4 + r]) * out_scale;
+            if (p.bias && nb + r < N) v[r] += p.bias[nb + r];
+            if (p.act == 1) v[r] = fmaxf(v[r], 0.f);
+            else if (p.act == 2) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
+        if (p.relu_mask) {
+            const bf16* mk = (const bf16*)p.relu_mask + m * p.ldmask + nb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (nb + r < N && !((float)mk[r] > 0.f)) v[r] = 0.f;
+        }
+        if (p.c_f32) {
+            float* c = (float*)p.C + m * p.ldc + nb;
+            if (nb + 3 < N && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < N) c[r] = v[r];
+            }
+        } else {
+            bf16* c = (bf16*)p.C + m * p.ldc + nb;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+            if (nb + 3 < N && (p.ldc & 3) == 0) *reinterpret_cast<bf16x4*>(c) = o;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < N) c[r] = o[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 __device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
@@ -830,6 +916,14 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     }
     STES_CHECK(!bnb, STES_ERR_UNSUPPORTED, "stes_gemm: the BatchNorm-backward prologue exists for the streaming shapes only "
                                            "(N in {32,64,128,160,320} or a multiple of 128 up to 1024, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
+    // no prologue and at most 2^28 multiply-adds: the latency-bound small kernel
+    if (!a->a_scale && !a->a_gate && a->k0 == 0 && a->map_stride <= 1 && !a->col_sum && a->n_split == 0 &&
+        (double)a->M * a->N * a->K <= (double)(1L << 28) && a->M <= 16L * 65535) {
+        hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)stes_div_up(a->M, 16), (unsigned)stes_div_up(a->N, 64)), dim3(256), 0,
+                           (hipStream_t)stream, *a);
+        STES_LAUNCH_CHECK();
+        return STES_OK;
+    }
     const int m_tiles = stes_div_up(a->M, BM);
     // fewer than 300 128-wide tiles (the head and squeeze-excite matrices: 1,024 rows) leave CUs idle: 64-wide tiles double
     // the workgroups (measured 20-30 % faster on those shapes)

@@ -220,6 +220,9 @@ def _gemm_kernel(a):
     if stream_ok:
         nb = _stream_slice(a.N)
         return "gemm_stream_kernel<%d, %d, %d>" % (nb // 16, 8 if nb >= 128 else 4, 2 if a.a_raw else (1 if a.a_gate else 0))
+    if (not a.a_scale and not a.a_gate and a.k0 == 0 and a.map_stride <= 1 and not a.col_sum and a.n_split == 0
+            and a.M * a.N * a.K <= (1 << 28) and a.M <= 16 * 65535):
+        return "gemm_small_kernel"
     wide = a.N > 64 and -(-a.M // 128) * -(-a.N // 128) >= 300 and not (a.N % 128 != 0 and a.N % 64 == 0)
     return "gemm_kernel<128>" if wide else "gemm_kernel<64>"
 

@@ -19,8 +19,15 @@ def _bf(*shape, g, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (300, 128, 64), (1000, 320, 128), (77, 7, 1536), (513, 768, 320), (256, 2304, 768)])
-def test_gemm_plain(M, N, K):
+@pytest.mark.parametrize("M,N,K,kernel", [
+    (128, 64, 32, "gemm_small_kernel"), (300, 128, 64, "gemm_small_kernel"), (1000, 320, 128, "gemm_small_kernel"),
+    (77, 7, 1536, "gemm_small_kernel"), (513, 768, 320, "gemm_small_kernel"), (1024, 80, 8, "gemm_small_kernel"),
+    (256, 2304, 768, "gemm_kernel<64>"),          # few 128-wide tiles -> 64-wide ones
+    (4100, 320, 328, "gemm_kernel<64>"),          # a width that is a multiple of 64 but not of 128
+    (16384, 384, 328, "gemm_kernel<128>"), (9000, 40, 1000, "gemm_kernel<64>")])
+def test_gemm_plain(M, N, K, kernel):
+    """Every dispatch target of the no-prologue product (the latency-bound small kernel up to 2^28 multiply-adds, the
+    tiled kernel with 64- or 128-wide tiles) against fp32 torch, bf16 and fp32 outputs, with bias."""
     from spot_amd import lib
     g = torch.Generator().manual_seed(M + N + K)
     A, W = _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5)
@@ -28,10 +35,35 @@ def test_gemm_plain(M, N, K):
     ref = A.float() @ W.float().t() + bias
     for out_dtype in (torch.bfloat16, torch.float32):
         C = torch.full((M, N), 7.0, dtype=out_dtype, device="cuda")
-        lib.gemm(dev(A), dev(W), C, M, N, K, bias=dev(bias))
+        lib.TIMING = []
+        try:
+            lib.gemm(dev(A), dev(W), C, M, N, K, bias=dev(bias))
+            assert [t[0] for t in lib.TIMING] == [kernel]
+        finally:
+            lib.TIMING = None
         torch.cuda.synchronize()
         tol = 2e-2 if out_dtype == torch.bfloat16 else 2e-3
         torch.testing.assert_close(C.float().cpu(), ref, rtol=tol, atol=tol)
+
+
+def test_gemm_small_kernel_epilogues():
+    """The small kernel's epilogue options as the squeeze-excite backward uses them: transposed weights with a padded
+    leading dimension, ReLU mask, output scale, fp32 output; sigmoid / ReLU activations; odd sizes."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(77)
+    M, N, K, ldw = 1000, 72, 200, 208
+    A = _bf(M, K, g=g)
+    Wp = torch.zeros(N, ldw, dtype=torch.bfloat16)
+    Wp[:, :K] = _bf(N, K, g=g, scale=K ** -0.5)
+    mask = _bf(M, N, g=g)
+    ref = (A.float() @ Wp[:, :K].float().t()) * 0.25 * (mask.float() > 0)
+    C = torch.full((M, N), 7.0, device="cuda")
+    lib.gemm(dev(A), dev(Wp), C, M, N, K, ldw=ldw, relu_mask=dev(mask), ldmask=N, out_scale=0.25)
+    torch.testing.assert_close(C.cpu(), ref, rtol=2e-3, atol=2e-3)
+    for act, fn in ((1, torch.relu), (2, torch.sigmoid)):
+        Cb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        lib.gemm(dev(A), dev(Wp), Cb, M, N, K, ldw=ldw, act=act)
+        torch.testing.assert_close(Cb.float().cpu(), fn(A.float() @ Wp[:, :K].float().t()), rtol=2e-2, atol=2e-2)
 
 
 def test_gemm_prologue_stats_compact_and_rowmap():
