@@ -12,6 +12,7 @@ torch supplies device memory, streams and (in spot_amd.dp) the RCCL process grou
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -684,11 +685,19 @@ class Engine:
         feat = self.feat_h
         p = lib.ptr
         loc = None
+        main = torch.cuda.current_stream()
+        loc_on_side = False
         if self.loc is not None:
-            l1, l2, l3 = self.loc
-            lib.gemm(feat, l1.w_bf, self.loc_h1, N, l1.N, l1.K, bias=l1.b, act=1)
-            lib.gemm(self.loc_h1, l2.w_bf, self.loc_h2, N, l2.N, l2.K, bias=l2.b)
-            lib.gemm(self.loc_h2, l3.w_bf, self.loc_out, N, l3.N, l3.K, bias=l3.b)
+            # the location MLP does not depend on the temporal head, and the recurrence (a hundred small dependent launches)
+            # leaves most of the GPU idle: the MLP runs beside it on the side stream
+            loc_on_side = OVERLAP and self.head_kind == "gru"
+            if loc_on_side:
+                self.side.wait_stream(main)
+            with torch.cuda.stream(self.side) if loc_on_side else contextlib.nullcontext():
+                l1, l2, l3 = self.loc
+                lib.gemm(feat, l1.w_bf, self.loc_h1, N, l1.N, l1.K, bias=l1.b, act=1)
+                lib.gemm(self.loc_h1, l2.w_bf, self.loc_h2, N, l2.N, l2.K, bias=l2.b)
+                lib.gemm(self.loc_h2, l3.w_bf, self.loc_out, N, l3.N, l3.K, bias=l3.b)
             loc = self.loc_out.view(B, T, 2)
         if self.head_kind == "gru":
             xin, in_dim = feat, Fd
@@ -721,6 +730,8 @@ class Engine:
         else:
             self.fc_in = feat
             lib.gemm(feat, self.fc.w_bf, self.logits, N, self.fc.N, Fd, bias=self.fc.b)
+        if loc_on_side:
+            main.wait_stream(self.side)
         return self.logits.view(B, T, self.fc.N), loc, feat.view(B, T, Fd)
 
     def _mul(self, a, m, out):
@@ -740,6 +751,27 @@ class Engine:
         dfb = None
         fc = self.fc
         ncp = dlogits_bf.shape[1]
+        has_loc = self.loc is not None and dloc_bf is not None
+
+        def loc_backward():
+            l1, l2, l3 = self.loc
+            lib.wgrad(dloc_bf, self.loc_h2, g(l3.w), N, l3.N, l3.K, ldp=8, dbias=g(l3.b))
+            dh2 = sc("loc.dh2", N * l2.N)
+            lib.gemm(dloc_bf, l3.wT_bf, dh2, N, l2.N, 8, ldw=l3.Np)
+            lib.wgrad(dh2, self.loc_h1, g(l2.w), N, l2.N, l2.K, dbias=g(l2.b))
+            dh1 = sc("loc.dh1", N * l1.N)
+            lib.gemm(dh2, l2.wT_bf, dh1, N, l1.N, l2.N, ldw=l2.Np, relu_mask=self.loc_h1, ldmask=l1.N)
+            lib.wgrad(dh1, self.feat_in, g(l1.w), N, l1.N, Fd, dbias=g(l1.b))
+            d = sc("dfeat.b", N * Fd, F32)
+            lib.gemm(dh1, l1.wT_bf, d, N, Fd, l1.N, ldw=l1.Np)
+            return d
+        # the location MLP's backward beside the recurrence's (see _heads_forward)
+        main0 = torch.cuda.current_stream()
+        loc_on_side = OVERLAP and has_loc and self.head_kind == "gru"
+        if loc_on_side:
+            self.side.wait_stream(main0)
+            with torch.cuda.stream(self.side):
+                dfb = loc_backward()
         if self.head_kind == "gru":
             Hh = self.gru_layers[-1].H
             in_dim = 2 * Hh
@@ -787,17 +819,10 @@ class Engine:
         else:
             lib.wgrad(dlogits_bf, self.feat_in, g(fc.w), N, fc.N, Fd, ldp=ncp, dbias=g(fc.b))
             lib.gemm(dlogits_bf, fc.wT_bf, dfa, N, Fd, ncp, ldw=fc.Np)
-        if self.loc is not None and dloc_bf is not None:
-            l1, l2, l3 = self.loc
-            lib.wgrad(dloc_bf, self.loc_h2, g(l3.w), N, l3.N, l3.K, ldp=8, dbias=g(l3.b))
-            dh2 = sc("loc.dh2", N * l2.N)
-            lib.gemm(dloc_bf, l3.wT_bf, dh2, N, l2.N, 8, ldw=l3.Np)
-            lib.wgrad(dh2, self.loc_h1, g(l2.w), N, l2.N, l2.K, dbias=g(l2.b))
-            dh1 = sc("loc.dh1", N * l1.N)
-            lib.gemm(dh2, l2.wT_bf, dh1, N, l1.N, l2.N, ldw=l2.Np, relu_mask=self.loc_h1, ldmask=l1.N)
-            lib.wgrad(dh1, self.feat_in, g(l1.w), N, l1.N, Fd, dbias=g(l1.b))
-            dfb = sc("dfeat.b", N * Fd, F32)
-            lib.gemm(dh1, l1.wT_bf, dfb, N, Fd, l1.N, ldw=l1.Np)
+        if has_loc and not loc_on_side:
+            dfb = loc_backward()
+        if loc_on_side:
+            main0.wait_stream(self.side)
         if dfeat_extra is not None:
             dfa.add_(dfeat_extra.reshape(-1).float())
         if self.ca is not None:
