@@ -14,14 +14,13 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-import math
 import os
 
 import torch
 import torch.nn as nn
 
 from . import lib
-from .model.modules import FCPrediction, GRUPrediction
+from .model.modules import GRUPrediction
 from .model.min_gru import MinRNNPredictor
 from .model.shift import GatedShift, TemporalShift
 from .regnet import ConvBnAct
