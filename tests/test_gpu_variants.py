@@ -1,4 +1,4 @@
-"""Variants and harness on the GPU: plain-shift + minGRU (BASELINE config 4), 3-layer GRU, padded last window,
+"""Variants and harness on the GPU: plain-shift + minGRU (-m rny008_tsm -t mingru), 3-layer GRU, padded last window,
 sliding-window inference with peak-picked events, and size-independent properties at the full benchmark size."""
 import numpy as np
 import pytest
@@ -290,7 +290,7 @@ def test_sliding_window_events_match_oracle():
 
 
 def test_full_size_properties():
-    """BASELINE size (16 clips x 64 frames x 224x224, 1024 frames): properties that need no oracle run.
+    """Benchmark size (16 clips x 64 frames x 224x224, 1024 frames): properties that need no oracle run.
     (1) conv3D = 0 -> the gated shift is the identity in source channel order, bit for bit;
     (2) training-mode BatchNorm: every normalised conv output has per-channel mean ~0 / variance ~1;
     (3) evaluation is deterministic (two runs bit-identical) and independent of the batch split (16 clips at once ==

@@ -185,7 +185,7 @@ def test_video_clip_layout_and_evaluate_with_a_stub_model(tmp_path):
 def test_sliding_window_accumulator_and_sharding():
     from spot_amd import infer
     from spot_amd.util.postproc import ScoreAccumulator
-    assert infer.num_windows(15000, 64, 64) == 235            # 25 fps x 10 min (BASELINE config 5)
+    assert infer.num_windows(15000, 64, 64) == 235            # 25 fps x 10 min: the long-video inference case
     assert infer.num_windows(10, 64, 64) == 1
     all_b = infer.window_batches(15000, 64, 16)
     assert len(all_b) == 15 and sum(len(b) for b in all_b) == 235 and all_b[-1][-1] == 234 * 64
