@@ -128,9 +128,10 @@ int stes_clip_gate_bwd(const float* da, const float* db, const uint16_t* x, cons
  * mask*c2, dA3*mask*c2 with mask = [scale*c2 + shift > 0]; dgate [N][C] = gradient at the SE gate.  With the SE backward's
  * dpool, stes_se_bwd_bnsums turns S into the two BatchNorm-backward sums of conv2.bn (what stes_bn_bwd_reduce would give
  * for dy = (dA3*gate + dpool)*mask; accumulated with atomics, the caller zeroes them), so that reduction pass over the
- * tensors is skipped.                                                                                                */
+ * tensors is skipped.  With gate and dpre (both or neither) it also writes dpre [N][C] = bf16(dgate * gate * (1 - gate)), the
+ * gradient at the sigmoid's input (what stes_sigmoid_bwd would give).                                               */
 int stes_se_bwd_pool(const uint16_t* c2, const float* scale, const float* shift, const uint16_t* dA3, float* S,
-                     float* dgate, int N, int HW, int C, void* stream);
+                     float* dgate, const float* gate, uint16_t* dpre, int N, int HW, int C, void* stream);
 int stes_se_bwd_bnsums(const float* S, const float* gate, const float* dpool, float* s_dy, float* s_dyr, int N, int C,
                        void* stream);
 

@@ -163,8 +163,8 @@ __global__ void chan_pool_kernel(const bf16* __restrict__ c, const float* __rest
 //                                                           sum dy*c2 = sum_n gate*S3 + dpool*S2     (se_bwd_bnsums_kernel)
 // so the BatchNorm reduction pass over the two tensors is not needed.
 __global__ void se_bwd_pool_kernel(const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   const bf16* __restrict__ dA, float* __restrict__ S, float* __restrict__ dgate, int N, int HW,
-                                   int C, int R) {
+                                   const bf16* __restrict__ dA, float* __restrict__ S, float* __restrict__ dgate,
+                                   const float* __restrict__ gate, bf16* __restrict__ dpre, int N, int HW, int C, int R) {
     extern __shared__ float lds[];     // [R][4][C]
     const int CH = C / 8;
     const int n = blockIdx.x;
@@ -200,7 +200,9 @@ __global__ void se_bwd_pool_kernel(const bf16* __restrict__ c, const float* __re
             for (int k = 0; k < 4; ++k) t[k] += lds[((long)r * 4 + k) * C + ch];
 #pragma unroll
         for (int k = 0; k < 4; ++k) S[((long)k * N + n) * C + ch] = t[k];
-        dgate[(long)n * C + ch] = scale[ch] * t[3] + shift[ch] * t[1];
+        const float dg = scale[ch] * t[3] + shift[ch] * t[1];
+        dgate[(long)n * C + ch] = dg;
+        if (dpre) { const float gv = gate[(long)n * C + ch]; dpre[(long)n * C + ch] = (bf16)(dg * gv * (1.f - gv)); }   // sigmoid backward
     }
 }
 
@@ -532,15 +534,16 @@ extern "C" int stes_chan_pool(const uint16_t* c, const float* scale, const float
 }
 
 extern "C" int stes_se_bwd_pool(const uint16_t* c2, const float* scale, const float* shift, const uint16_t* dA3, float* S,
-                                float* dgate, int N, int HW, int C, void* stream) {
+                                float* dgate, const float* gate, uint16_t* dpre, int N, int HW, int C, void* stream) {
     STES_CHECK(c2 && scale && shift && dA3 && S && dgate && N > 0 && HW > 0, STES_ERR_ARG, "stes_se_bwd_pool: null pointer");
+    STES_CHECK(!dpre || gate, STES_ERR_ARG, "stes_se_bwd_pool: dpre needs the gate");
     STES_CHECK(C % 8 == 0 && C / 8 <= TPB, STES_ERR_ARG, "stes_se_bwd_pool: C must be a multiple of 8, at most 2048");
     const int CH = C / 8;
     int R = TPB / CH;
     if (R > HW) R = HW;
     if (R < 1) R = 1;
     hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(N), dim3(CH * R), (size_t)R * 4 * C * sizeof(float), S(stream), (const bf16*)c2, scale, shift,
-                       (const bf16*)dA3, S, dgate, N, HW, C, R);
+                       (const bf16*)dA3, S, dgate, gate, (bf16*)dpre, N, HW, C, R);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

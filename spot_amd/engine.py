@@ -238,10 +238,10 @@ class Block:
         # --- squeeze-excite backward
         dgate = sc("se.dgate", self.N * cmid, F32)
         S4 = sc("se.S4", 4 * self.N * cmid, F32)
-        lib.call("stes_se_bwd_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(S4), p(dgate), self.N, HWo, cmid)
         dpre2, dpre1, dpool = sc("se.dpre2", self.N * cmid), sc("se.dpre1", self.N * self.rd), sc("se.dpool", self.N * cmid, F32)
         se, rd = self.se, self.rd
-        lib.call("stes_sigmoid_bwd", p(dgate), p(self.segate), p(dpre2), self.N * cmid)
+        lib.call("stes_se_bwd_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(S4), p(dgate), p(self.segate), p(dpre2),
+                 self.N, HWo, cmid)
         lib.gemm(dpre2, self.se2.wT_bf, dpre1, self.N, rd, cmid, ldw=self.se2.Np, relu_mask=self.hidden, ldmask=rd)
         lib.gemm(dpre1, self.se1.wT_bf, dpool, self.N, cmid, rd, ldw=self.se1.Np, out_scale=1.0 / HWo)
         def se_wgrads():

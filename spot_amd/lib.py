@@ -77,7 +77,7 @@ _SIGS = {
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
     "stes_clip_gate_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
     "stes_clip_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
-    "stes_se_bwd_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stes_se_bwd_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_se_bwd_bnsums": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "stes_bn_bwd_reduce": [_P, _P],
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],

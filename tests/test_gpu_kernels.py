@@ -236,11 +236,14 @@ def test_se_backward_pool_gives_gate_gradient_and_bn_sums(Cc, HW):
     dgate_ref = (torch.relu(pre) * d).sum(1)
     dy = (d * gate[:, None] + dpool[:, None]) * (pre > 0)
     S = torch.empty(4, N, Cc, device="cuda"); dg = torch.empty(N, Cc, device="cuda")
-    lib.call("stes_se_bwd_pool", lib.ptr(dev(c2)), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dev(dA)), lib.ptr(S), lib.ptr(dg), N, HW, Cc)
+    dpre = torch.empty(N, Cc, dtype=BF, device="cuda")
+    lib.call("stes_se_bwd_pool", lib.ptr(dev(c2)), lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(dev(dA)), lib.ptr(S), lib.ptr(dg),
+             lib.ptr(dev(gate)), lib.ptr(dpre), N, HW, Cc)
     s_dy = torch.zeros(Cc, device="cuda"); s_dyr = torch.zeros(Cc, device="cuda")
     lib.call("stes_se_bwd_bnsums", lib.ptr(S), lib.ptr(dev(gate)), lib.ptr(dev(dpool)), lib.ptr(s_dy), lib.ptr(s_dyr), N, Cc)
     torch.cuda.synchronize()
     close(dg, dgate_ref, 1e-3, 1e-3)
+    close(dpre.float(), dgate_ref * gate * (1 - gate), 1e-2, 1e-2)      # the sigmoid backward on the way out (bf16)
     close(s_dy, dy.sum((0, 1)), 1e-3, 1e-3)
     close(s_dyr, (dy * x).sum((0, 1)), 1e-3, 2e-3)
 
