@@ -110,9 +110,9 @@ int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, co
                    uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream);
 
 /* Squeeze-excite (timm SEModule inside regnety_008's Bottleneck: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid) runs on
- * stes_chan_pool + two stes_gemm calls (bias + ReLU / sigmoid epilogues); its backward on stes_sigmoid_bwd + two
- * stes_gemm (relu_mask, out_scale = 1/HW) + two stes_wgrad calls.
- * stes_sigmoid_bwd: out[i] = bf16(d[i] * g[i] * (1 - g[i])), the gradient at the sigmoid's input.                */
+ * stes_chan_pool + two stes_gemm calls (bias + ReLU / sigmoid epilogues); its backward on stes_se_bwd_pool (which also
+ * applies the sigmoid's derivative) + two stes_gemm (relu_mask, out_scale = 1/HW) + two stes_wgrad calls.
+ * stes_sigmoid_bwd: out[i] = bf16(d[i] * g[i] * (1 - g[i])), the gradient at a sigmoid's input, on its own.      */
 int stes_sigmoid_bwd(const float* d, const float* g, uint16_t* out, int64_t n, void* stream);
 /* Channel attention over a clip (reference model/modules.py:86-105 ChannelAttention, applied to the frame features at
  * train_e2e_spatial.py:437-438): mean over the T frames (stes_chan_pool with HW = T) -> two bias-free stes_gemm calls
