@@ -246,6 +246,12 @@ typedef struct {
 } stes_gru_args;
 int stes_gru_forward(const stes_gru_args* a, void* stream);
 int stes_gru_backward(const stes_gru_args* a, void* stream);
+/* stes_gru_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as stes_gru_forward,
+ * except that a->hstate is ignored (may be NULL): the fp32 hidden-state ping-pong buffer is a 1 MiB array inside the
+ * library, one copy per GPU, so B*H <= 65536 (else STES_ERR_UNSUPPORTED).  Calls no hipMalloc/hipFree.  All calls on one
+ * GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not. */
+int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream);
 /* MinGRU recurrence, reference model/min_gru.py:76-92; pre = [gate pre-activation | candidate]; h0 [H] is the layer's
  * frozen initial-state parameter (:42,60; NULL = zeros). */
 int stes_mingru_scan_fwd(const uint16_t* pre, const float* h0, uint16_t* h, int B, int T, int H, void* stream);

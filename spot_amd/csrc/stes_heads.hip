@@ -7,6 +7,7 @@
 // batch rows, its 4 waves split K = H for the [B,H] x [H,3*16] product on
 // v_mfma_f32_16x16x32_bf16 with the hidden state as the A operand (read straight from the output
 // sequence) and the W_hh rows as B, then the gate math runs on the accumulator layout.
+#include <mutex>
 #include "stes_common.h"
 
 namespace {
@@ -352,6 +353,45 @@ extern "C" int stes_gru_forward(const stes_gru_args* a, void* stream) {
     STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward: saved needs hprev_bf");
     const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
     for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+// ------------------------------------------------------------------ GRU forward for callers that cannot allocate
+// The fp32 hidden-state ping-pong buffer ([2 dirs][2][B][H], the `hstate` workspace of stes_gru_forward) lives in this
+// file-scope device array instead of caller memory.  Every GPU holds its own copy at its own address: the address is
+// resolved once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+constexpr long GRU_SCRATCH_FLOATS = 1L << 18;                 // 1 MiB per GPU: 4*B*H floats, i.e. B*H <= 65,536
+static __device__ __align__(256) float scratch[GRU_SCRATCH_FLOATS];
+constexpr int MAX_DEVICES = 64;
+static float* g_scratch_ptr[MAX_DEVICES];                      // per device, resolved on the first call there
+static std::mutex g_scratch_mu;
+
+extern "C" int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream) {
+    STES_CHECK(a && a->gi && a->whh && a->bhh && a->y, STES_ERR_ARG, "stes_gru_forward_noalloc: null pointer");
+    STES_CHECK(a->H > 0 && a->H % 32 == 0 && a->B > 0 && a->T > 0, STES_ERR_ARG, "stes_gru_forward_noalloc: H must be a positive multiple of 32");
+    STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward_noalloc: saved needs hprev_bf");
+    STES_CHECK(4L * a->B * a->H <= GRU_SCRATCH_FLOATS, STES_ERR_UNSUPPORTED,
+               "stes_gru_forward_noalloc: B*H exceeds the static scratch (B*H <= 65536); use stes_gru_forward with a caller workspace");
+    int dev = -1;
+    STES_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES, STES_ERR_UNSUPPORTED,
+               "stes_gru_forward_noalloc: cannot identify the current device");
+    float* ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {
+            void* sym = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !sym) return stes_set_error(STES_ERR_LAUNCH, hipGetErrorString(e));
+            g_scratch_ptr[dev] = (float*)sym;
+        }
+        ptr = g_scratch_ptr[dev];
+    }
+    // nothing in the buffer has to start at zero: step 0 takes h = 0 without reading it, step s reads what step s-1 wrote
+    stes_gru_args b = *a;
+    b.hstate = ptr;
+    const dim3 grid(b.H / 16, 2, stes_div_up(b.B, 16));
+    for (int s = 0; s < b.T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, S(stream), b, s);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

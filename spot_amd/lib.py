@@ -101,6 +101,7 @@ _SIGS = {
     "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gru_forward": [_P, _P],
     "stes_gru_backward": [_P, _P],
+    "stes_gru_forward_noalloc": [_P, _P],
     "stes_mingru_scan_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
     "stes_mingru_scan_bwd": [_P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
     "stes_dropout": [_P, _P, _P, _I64, _F32, _U32, _P],

@@ -1,0 +1,42 @@
+"""The entry point that allocates nothing (stes_gru_forward_noalloc, hidden-state workspace in a static device array)
+against stes_gru_forward on the same inputs, through the C-ABI: outputs must be bit-identical, on two calls in a row,
+the second with a smaller input (the static array then still holds the first call's state)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _run(entry, B, T, H, seed, with_saved):
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(seed)
+    gi = (torch.randn(B, T, 2, 3 * H, generator=g) * 0.7).to(BF).cuda()
+    whh = (torch.randn(2, 3 * H, H, generator=g) / H ** 0.5).to(BF).cuda()
+    bhh = (torch.randn(2, 3 * H, generator=g) * 0.1).cuda()
+    y = torch.full((B, T, 2 * H), 7.0, dtype=BF, device="cuda")
+    saved = torch.full((2, T, B, 5, H), 7.0, device="cuda") if with_saved else None
+    hprev = torch.full((2, T, B, H), 7.0, dtype=BF, device="cuda") if with_saved else None
+    # stes_gru_forward gets its workspace from the caller; the other entry point must not need one
+    hstate = torch.zeros(2, 2, B, H, device="cuda") if entry == "stes_gru_forward" else None
+    a = lib.gru_args(gi=gi, whh=whh, whhT=None, bhh=bhh, y=y, hstate=hstate, saved=saved, hprev_bf=hprev, B=B, T=T, H=H)
+    lib.check(getattr(lib.lib(), entry)(C.byref(a), lib.stream()), entry)
+    torch.cuda.synchronize()
+    return y, saved, hprev
+
+
+def test_gru_forward_noalloc_matches_workspace_version():
+    from spot_amd import lib
+    for (B, T, H, seed, sv) in ((16, 64, 768, 0, True), (3, 9, 64, 1, False)):      # second call: smaller input
+        y0, s0, h0 = _run("stes_gru_forward", B, T, H, seed, sv)
+        y1, s1, h1 = _run("stes_gru_forward_noalloc", B, T, H, seed, sv)
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        assert float(y0.float().abs().max()) > 0.05 and bool((y0.float().abs() <= 1.0).all())
+        if sv:
+            assert torch.equal(s0, s1) and torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+    # beyond the static array's size the entry point refuses instead of overrunning it
+    a = lib.gru_args(gi=y0, whh=y0, whhT=None, bhh=y0, y=y0, hstate=None, saved=None, hprev_bf=None, B=1024, T=1, H=128)
+    rc = lib.lib().stes_gru_forward_noalloc(C.byref(a), lib.stream())
+    assert rc == -3 and b"exceeds" in lib.lib().stes_last_error()
