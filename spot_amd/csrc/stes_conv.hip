@@ -9,6 +9,7 @@
 //             statistics of the output reduced in registers (one atomic per channel per wave);
 //   dgrad   : same kernel, transposed/stride-aware tap geometry;
 //   wgrad   : reduction over pixels -> both operands transposed through LDS with ds_read_b64_tr_b16.
+#include <mutex>
 #include "stes_common.h"
 
 namespace {
@@ -746,6 +747,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             const int form = mode == 1 ? 2 : (stride == 1 ? 0 : 1);
             static size_t seen_lds[3][8];
             static int seen_val[3][8], n_seen[3] = {0, 0, 0};
+            static std::mutex mu;                  // entry points may be called from any host thread
+            std::lock_guard<std::mutex> lock(mu);
             int resident = 0;
             for (int i = 0; i < n_seen[form]; ++i) if (seen_lds[form][i] == lds) resident = seen_val[form][i];
             if (resident == 0) {
@@ -784,6 +787,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         STES_CHECK(big || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_conv3x3g_dgrad: cannot raise the dynamic LDS limit");
         static size_t seen_lds[8]; static int seen_val[8], n_seen = 0;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
         int resident = 0;
         for (int i = 0; i < n_seen; ++i) if (seen_lds[i] == lds) resident = seen_val[i];
         if (resident == 0) {

@@ -11,6 +11,7 @@
 //             consumed transposed: tiles land in LDS row-major and are fetched with
 //             ds_read_b64_tr_b16 straight into MFMA fragment order.
 #include <cstdlib>
+#include <mutex>
 #include "stes_common.h"
 
 namespace {
@@ -838,6 +839,8 @@ static size_t wgrad_lds_bytes() {
 // Workgroups of one streaming-GEMM instantiation resident per CU at a given dynamic LDS size (cached: queried once per size).
 template <int NI, int WAVES, int PRO>
 static int stream_residency(size_t lds) {
+    static std::mutex mu;                          // entry points may be called from any host thread (autograd runs backward on its own)
+    std::lock_guard<std::mutex> lock(mu);
     static bool attr_done = false;
     static size_t seen[8];
     static int val[8];

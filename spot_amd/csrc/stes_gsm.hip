@@ -54,12 +54,8 @@ struct GateTile {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
-#ifdef STES_GATE_NO_DOT2
-    return acc + __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
-#else
     asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "s"(b), "v"(a));
     return acc;
-#endif
 }
 
 // HALF: channels per group as a compile-time constant (0: read from the geometry).  With it the channel loop unrolls, the

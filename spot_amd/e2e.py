@@ -56,7 +56,7 @@ class _EngineFn(torch.autograd.Function):
         if ctx.has_loc and dloc is not None:
             dlc = torch.zeros(N, 8, dtype=BF, device=dlogits.device)
             dlc[:, :2] = dloc.reshape(N, 2)
-        extra = dfeat if (dfeat is not None and bool(dfeat.any())) else None
+        extra = dfeat            # the gradient w.r.t. the returned features (zeros when they are unused) is added on the device
         eng.backward(dl, dlc, extra)
         return None, None, None
 

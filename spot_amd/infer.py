@@ -15,8 +15,6 @@ import torch
 
 from .util.postproc import ScoreAccumulator, events_from_scores, filter_events_by_score, non_max_suppression_events
 
-DEFAULT_CLASSES = ["serve", "receive", "set", "attack", "block", "score", "ball_hit_ground", "net_touch", "out"]
-
 
 def num_windows(n_frames, window, stride):
     """reference inference_on_mp4.py:174"""

@@ -58,7 +58,7 @@ def get_args(argv=None):
     p.add_argument("-s", "--save_dir", type=str, required=True)
     p.add_argument("--resume", action="store_true")
     p.add_argument("--predict_location", action="store_true")
-    p.add_argument("--criterion", choices=["map", "loss"], default="loss")
+    p.add_argument("--criterion", choices=["map", "loss"], default="map")      # the reference's default (train_e2e_spatial.py:136)
     p.add_argument("--start_val_epoch", type=int, default=30)
     p.add_argument("--time_backward", action="store_true")
     p.add_argument("--use_channel_attention", action="store_true")
@@ -282,6 +282,17 @@ def fused_epoch(trainer, loader, lr_scheduler, device, with_xy=True):
     return {"sum": s, "cls": c, "loc": l, "contrast": 0.0}
 
 
+def scaler_state(scaler):
+    """State dict for the optimizer file.  The reference resumes with optimizer, scaler and scheduler state inside one
+    `try` (train_e2e_spatial.py:966-976) and its GradScaler is enabled: an empty dict (what a disabled scaler returns; bf16
+    needs no loss scaling) would raise there after the optimizer has loaded and before the scheduler does.  So a disabled
+    scaler is written as a fresh enabled one's state, which any GradScaler loads."""
+    sd = scaler.state_dict() if scaler is not None else {}
+    if not sd:
+        sd = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+    return sd
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main(args):
     from .e2e import E2EModel
@@ -324,12 +335,20 @@ def main(args):
             train_loss = fused_epoch(trainer, train_loader, lr_scheduler, args.device, args.predict_location)
         else:
             train_loss = model.epoch(train_loader, optimizer, scaler, lr_scheduler=lr_scheduler, acc_grad_iter=args.acc_grad_iter)
+        if dist is not None:
+            # BatchNorm running statistics are rank-local during training; validation, evaluation and the checkpoint all
+            # use rank 0's, so that the criterion describes the weights that are saved
+            for b in model._model.buffers():
+                if b.dtype.is_floating_point:
+                    dist.broadcast(b, src=0)
         val_loss = model.epoch(val_loader, acc_grad_iter=args.acc_grad_iter)
-        if dist is not None:                                 # every rank saw its own shard: average the reported losses
-            t = torch.tensor([train_loss[k] for k in ("sum", "cls", "loc")] + [val_loss[k] for k in ("sum", "cls", "loc")],
+        if dist is not None:
+            # train: every rank's loss is already divided by the GLOBAL denominators (dp.loss_denominators), i.e. it is
+            # this rank's part of the global-batch loss -> sum; validation: per-rank means over equal shards -> average
+            t = torch.tensor([train_loss[k] for k in ("sum", "cls", "loc")] + [val_loss[k] / world for k in ("sum", "cls", "loc")],
                              device=args.device, dtype=torch.float64)
             dist.all_reduce(t)
-            t = (t / world).tolist()
+            t = t.tolist()
             train_loss.update(zip(("sum", "cls", "loc"), t[:3])); val_loss.update(zip(("sum", "cls", "loc"), t[3:]))
         if rank == 0:
             print("Epoch {}: train cls {:.5f} loc {:.5f} sum {:.5f} | val cls {:.5f} loc {:.5f} sum {:.5f}".format(
@@ -357,7 +376,7 @@ def main(args):
             if fused:
                 export_adamw_state(model, optimizer)
             torch.save({"optimizer_state_dict": optimizer.state_dict(),
-                        "scaler_state_dict": scaler.state_dict() if scaler is not None else {},
+                        "scaler_state_dict": scaler_state(scaler),
                         "lr_state_dict": lr_scheduler.state_dict()}, os.path.join(args.save_dir, "optim_{:03d}.pt".format(epoch)))
             store_config(os.path.join(args.save_dir, "config.json"), args, num_epochs, classes)
         if dist is not None:

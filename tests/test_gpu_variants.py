@@ -348,7 +348,8 @@ def test_train_driver_runs_checkpoints_and_resumes(tmp_path):
     import os
     from spot_amd import train as TR
     base = ["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "gru", "--clip_len", "4", "--crop_dim", "64", "--batch_size", "2",
-            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6"]
+            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6",
+            "--criterion", "loss"]
     model, losses, best = TR.main(TR.get_args(base + ["--num_epochs", "2"]))
     names = set(os.listdir(tmp_path))
     assert {"checkpoint_000.pt", "checkpoint_001.pt", "optim_001.pt", "loss.json", "config.json"} <= names and "optim_000.pt" not in names
@@ -369,7 +370,7 @@ def test_train_driver_runs_checkpoints_and_resumes(tmp_path):
     for split, seed in (("train", 0), ("val", 1)):
         b = list(TR.SyntheticClips(4, 4, 4, 64, 7, seed))[0]
         np.savez(shard_dir / f"{split}_000.npz", frame=b["frame"].numpy(), label=b["label"].numpy(), xy=b["xy"].numpy())
-    args = TR.get_args(["ds", str(shard_dir)] + base[2:-4] + ["-s", str(tmp_path / "run2"), "--num_classes", "6", "--num_epochs", "2"])
+    args = TR.get_args(["ds", str(shard_dir)] + base[2:-6] + ["-s", str(tmp_path / "run2"), "--num_classes", "6", "--num_epochs", "2", "--criterion", "loss"])
     _, losses3, _ = TR.main(args)
     assert len(losses3) == 2 and np.isfinite(losses3[1]["val"])
 
@@ -418,7 +419,8 @@ def test_train_driver_fused_mode_and_cross_mode_resume(tmp_path):
     import os
     from spot_amd import train as TR
     base = ["ds", "synthetic:8", "-m", "rny008_gsm", "-t", "mingru", "--clip_len", "4", "--crop_dim", "64", "--batch_size", "2",
-            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6"]
+            "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path), "--num_classes", "6",
+            "--criterion", "loss"]
     model, losses, _ = TR.main(TR.get_args(base + ["--num_epochs", "2", "--fused"]))
     assert [l["epoch"] for l in losses] == [0, 1] and all(np.isfinite(l["train"]) and np.isfinite(l["val"]) for l in losses)
     opt = torch.load(tmp_path / "optim_001.pt", weights_only=True)
@@ -484,7 +486,7 @@ def test_inference_cli_on_predecoded_frames_reads_the_training_drivers_files(tmp
     from spot_amd import infer, train as TR
     model, _, _ = TR.main(TR.get_args(["ds", "synthetic:4", "-m", "rny008_gsm", "-t", "deeper_gru", "--clip_len", "8", "--crop_dim", "64",
                                        "--batch_size", "2", "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s",
-                                       str(tmp_path / "run"), "--num_classes", "9", "--num_epochs", "2", "--time_backward"]))
+                                       str(tmp_path / "run"), "--num_classes", "9", "--num_epochs", "2", "--time_backward", "--criterion", "loss"]))
     frames = torch.randint(0, 256, (21, 3, 64, 64), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
     np.save(tmp_path / "v.npy", frames.numpy())
     ev = infer.main(["--frames", str(tmp_path / "v.npy"), "--checkpoint_path", str(tmp_path / "run" / "checkpoint_001.pt"),

@@ -182,31 +182,6 @@ def test_video_clip_layout_and_evaluate_with_a_stub_model(tmp_path):
     assert EV.evaluate(stub, ds, "VAL", classes, predict_location=False, quiet=True) == 1.0
 
 
-def test_standalone_evaluator_reads_the_prediction_files(tmp_path, golden, capsys):
-    """python -m spot_amd.eval (the reference's eval.py): a model directory with pred-test.N / pred-val.N recall files and a
-    truth file; the numbers are those of compute_mAPs before and after the windowed peak picking."""
-    import gzip
-    from spot_amd import eval as EV
-    from spot_amd.util import eval as E, score as S
-    z = golden("scores")
-    truth, pred = json.loads(str(z["truth"])), json.loads(str(z["pred"]))
-    d = tmp_path / "model"
-    os.makedirs(d)
-    for name in ("pred-test.3", "pred-test.7", "pred-val.7"):
-        with gzip.open(d / (name + ".recall.json.gz"), "wt", encoding="ascii") as fp:
-            json.dump(pred if name != "pred-test.3" else [], fp)
-    json.dump(truth, open(tmp_path / "val.json", "w"))
-    assert EV.get_pred_file(str(d), "test")[1] == 7
-    a = EV.get_args([str(d), "-s", "val", "--truth", str(tmp_path / "val.json"), "-t", "0", "1", "2", "--nms_window", "2"])
-    no_nms, nms = EV.main(**vars(a))
-    out = capsys.readouterr().out
-    assert "pred-val.7.recall.json.gz" in out and "(w/ NMS)" in out
-    assert no_nms[0] == S.compute_mAPs(truth, pred, [0, 1, 2], quiet=True)[0]
-    assert nms[0] == S.compute_mAPs(truth, E.non_maximum_supression(pred, 2), [0, 1, 2], quiet=True)[0] and nms[0] != no_nms[0]
-    with pytest.raises(FileNotFoundError):
-        EV.get_pred_file(str(tmp_path), "test")
-
-
 def test_sliding_window_accumulator_and_sharding():
     from spot_amd import infer
     from spot_amd.util.postproc import ScoreAccumulator
@@ -346,7 +321,7 @@ def test_train_driver_schedule_and_resume_rules(tmp_path):
     when nothing was dropped."""
     from spot_amd import train as TR
     args = TR.get_args(["ds", "synthetic:8", "-m", "rny008_gsm", "-s", str(tmp_path), "--num_epochs", "5", "--warm_up_epochs", "2",
-                        "--num_classes", "6", "--resume"])
+                        "--num_classes", "6", "--resume", "--criterion", "loss"])
     w = torch.nn.Parameter(torch.zeros(3))
     w.grad = torch.ones(3)
     opt = torch.optim.AdamW([{"params": w, "lr": 1e-3}])
@@ -380,3 +355,16 @@ def test_train_driver_schedule_and_resume_rules(tmp_path):
     torch.save({k: v for k, v in sd.items() if "_fc_out" not in k}, tmp_path / "checkpoint_003.pt")
     TR.load_from_save(args, m, opt2, None, sched2)
     assert len(opt2.state_dict()["state"]) == 1 and sched2.state_dict()["_schedulers"][0]["last_epoch"] == 50
+
+
+def test_optimizer_file_scaler_state_loads_into_an_enabled_grad_scaler():
+    """The reference resumes optimizer, GradScaler and scheduler inside one `try` (train_e2e_spatial.py:966-976) with an
+    ENABLED scaler, which refuses an empty state dict: the disabled scaler of the bf16 path is saved as a loadable state."""
+    from spot_amd import train as TR
+    sd = TR.scaler_state(torch.amp.GradScaler("cpu", enabled=False))
+    enabled = torch.amp.GradScaler("cpu")
+    with pytest.raises(RuntimeError):
+        enabled.load_state_dict({})
+    enabled.load_state_dict(sd)
+    assert enabled.state_dict()["scale"] == 65536.0
+    assert TR.scaler_state(enabled) == enabled.state_dict() and TR.scaler_state(None) == sd
