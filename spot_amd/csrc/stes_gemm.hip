@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "stes_common.h"
+#include "stes_gemm_stream.h"
 
 namespace {
 
@@ -268,264 +269,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         for (int t = tid; t < 2 * BN; t += 256) {
             const int which = t / BN, nl = t - which * BN;
             if (n0 + nl < N) atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[which * BN + nl] + red[(2 + which) * BN + nl]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ streaming GEMM for small K, N (weights resident in LDS)
-// The tall-and-skinny layers (K <= 320, column slice NB <= 160) are bound by HBM, not by MFMA.  Here the weight slice
-// [NB][K] sits in LDS for the workgroup's lifetime and every wave streams its own 32-row tiles with no workgroup barrier:
-// A fragments go global -> registers in MFMA operand layout (lane (fr,fq): row fr, k = 8fq..8fq+7: one 16-byte load), four
-// k-steps ahead of their use; the BatchNorm/ReLU/gate prologue runs in registers.  The output tile is staged through a
-// wave-private LDS buffer so that it leaves as whole rows (1 KiB per store instruction) and so that the BatchNorm
-// statistics of the rounded output cost 16 registers per lane (a lane always reads back the same 8 columns).
-#ifndef STES_STREAM_DEPTH
-#define STES_STREAM_DEPTH 4
-#endif
-// PRO selects the operand prologue: 0 none or BatchNorm+ReLU (a_scale/a_shift), 1 the same plus the squeeze-excite gate,
-// 2 BatchNorm backward: A is the gradient at a BatchNorm's output, a_raw the raw tensor under that BatchNorm, and the operand
-// is bf16(alpha*A + beta*a_raw + delta) -- what stes_bn_bwd_apply would have written; it is written here too (a_out, by the
-// workgroups of column slice 0) for the weight-gradient kernel, which saves that kernel's pass and one read of its result.
-template <int NI, int WAVES, int PRO>   // NB = 16*NI columns per workgroup
-__global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
-                                                                 RowDivs dv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool GATE = PRO == 1, BNB = PRO == 2;
-    constexpr int NB = NI * 16, D = STES_STREAM_DEPTH;
-    constexpr int CPR = NB / 8;                 // 16-byte chunks per output row
-    constexpr int RPP = 64 / CPR;               // output rows per store pass of a wave
-    constexpr int SRS = NB * 2 + 16;            // staging row stride (bytes)
-    const int K = p.K, N = p.N, nk = K >> 5;
-    const long M = p.M;
-    const int RS = 2 * K + 32;                  // weight row stride (bytes): (RS/16) % 4 == 2 keeps the b128 fragment reads conflict-free
-    unsigned char* wl = smem;
-    unsigned char* stage = smem + NB * RS + (threadIdx.x >> 6) * 16 * SRS;
-    float* sc_s = reinterpret_cast<float*>(smem + NB * RS + WAVES * 16 * SRS);
-    float* sh_s = sc_s + K;
-    float* red = sh_s + K;                      // [2][NB]
-    float* de_s = red + 2 * NB;                 // [K], BNB only (sc_s = alpha, sh_s = beta, de_s = delta)
-    // GATE only: this wave's copy of the gate rows of the (at most two) images its current tile touches, refreshed once per
-    // tile -- read at the point of use from global memory the gate cost a cache round trip in every k-step
-    // (it lives in the wave's output staging buffer: the gate is read in the k loop, the staging buffer in the tile epilogue)
-    float* gl = reinterpret_cast<float*>(stage);               // [2][K]: 8*K bytes <= 16*SRS since K <= 2*NB + 16
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int slice = idx % n_slices;
-    const int slot = (idx / n_slices) * 8 + xcd;
-    const int n0 = slice * NB;
-    const bf16* __restrict__ A = (const bf16*)p.A;
-    const bf16* __restrict__ A0 = (const bf16*)p.A0;
-    const bf16* __restrict__ R = (const bf16*)p.a_raw;
-    const bool has_affine = !BNB && p.a_scale != nullptr;
-    const bool stats = p.col_sum != nullptr;
-    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
-
-    {   // weight slice, prologue constants, statistics scratch
-        const bf16* __restrict__ W = (const bf16*)p.W;
-        const int kch = K >> 3;
-        for (int c = tid; c < NB * kch; c += WAVES * 64) {
-            const int r = c / kch, kc = c - r * kch;
-            const bf16x8 v = (n0 + r < N) ? *reinterpret_cast<const bf16x8*>(W + (long)(n0 + r) * p.ldw + kc * 8) : zero8();
-            *reinterpret_cast<bf16x8*>(wl + r * RS + kc * 16) = v;
-        }
-        if (has_affine) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.a_scale[k]; sh_s[k] = p.a_shift[k]; }
-        if (BNB) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.bn_alpha[k]; sh_s[k] = p.bn_beta[k]; de_s[k] = p.bn_delta[k]; }
-        for (int k = tid; k < 2 * NB; k += WAVES * 64) red[k] = 0.f;
-    }
-    __syncthreads();
-    if (slot >= m_slots) return;
-
-    // ---- cursors: the fetch cursor runs D k-steps ahead of the compute cursor
-    const long tstride = (long)m_slots * WAVES;
-    long f_tile = (long)slot * WAVES + wave, c_tile = f_tile;
-    int f_ks = 0, c_ks = 0;
-    const bf16* f_a[2]; const bf16* f_a0[2]; const bf16* f_r[2];
-    auto f_rows = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long m = f_tile * 32 + j * 16 + fr;
-            f_a[j] = nullptr; f_a0[j] = nullptr; f_r[j] = nullptr;
-            if (f_tile < row_tiles && m < M) {
-                long src = m;
-                if (p.map_stride > 1) {
-                    uint32_t n, rem, ho, wo;
-                    fdivmod((uint32_t)m, dv.hw, n, rem);
-                    fdivmod(rem, dv.wo, ho, wo);
-                    src = ((long)n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
-                }
-                f_a[j] = A + src * p.lda;
-                if (A0) f_a0[j] = A0 + src * p.lda0;
-                if (BNB) f_r[j] = R + src * p.lda;
-            }
-        }
-    };
-    const float* c_gate[2] = {nullptr, nullptr};
-    auto c_rows = [&]() {
-        if (GATE) {
-            if (c_tile >= row_tiles) return;
-            long m0 = c_tile * 32, m1 = m0 + 31;
-            if (m1 >= M) m1 = M - 1;
-            const uint32_t i0 = fdiv((uint32_t)m0, dv.gate), i1 = fdiv((uint32_t)m1, dv.gate);      // i1 <= i0 + 1 (gate_group >= 32)
-            __builtin_amdgcn_wave_barrier();                    // the previous tile's reads of gl are done
-            for (int c = lane; c < K / 2; c += 64) {            // 2 rows x K floats as float4 chunks
-                const int r = c >= K / 4, cc = c - r * (K / 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p.a_gate + (long)(r ? i1 : i0) * K + cc * 4);
-                *reinterpret_cast<f32x4*>(gl + r * K + cc * 4) = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                long m = m0 + j * 16 + fr;
-                if (m >= M) m = M - 1;
-                c_gate[j] = gl + (fdiv((uint32_t)m, dv.gate) - i0) * K;
-            }
-        }
-    };
-    bf16x8 ring[D][2];
-    bf16x8 ring_r[BNB ? D : 1][2];
-    auto fetch = [&](int d) {
-        const int k = f_ks * 32 + fq * 8;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (f_a[j] != nullptr) ring[d][j] = *reinterpret_cast<const bf16x8*>((k < p.k0 ? f_a0[j] : f_a[j]) + k);
-            else ring[d][j] = zero8();
-            if (BNB) ring_r[d][j] = f_r[j] != nullptr ? *reinterpret_cast<const bf16x8*>(f_r[j] + k) : zero8();
-        }
-        if (++f_ks == nk) { f_ks = 0; f_tile += tstride; f_rows(); }
-    };
-
-    f32x4 acc[NI][2];
-    float ssum[8], ssq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-    const int o_chunk = lane % CPR, o_rsub = lane / CPR;        // store phase: this lane's 8 columns and row phase
-    const bool o_active = o_rsub < RPP;
-
-    f_rows(); c_rows();
-#pragma unroll
-    for (int d = 0; d < D; ++d) fetch(d);
-
-    while (c_tile < row_tiles) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (c_tile >= row_tiles) break;
-            if (c_ks == 0) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            }
-            // ---- prologue on the two A fragments of this k-step
-            bf16x8 fb[2] = {ring[d][0], ring[d][1]};
-            const int k = c_ks * 32 + fq * 8;
-            if (BNB) {
-                float al[8], be[8], de[8];
-                load8f(sc_s + k, al); load8f(sh_s + k, be); load8f(de_s + k, de);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float f[8], r[8];
-                    unpack8(fb[j], f);
-                    unpack8(ring_r[d][j], r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = al[e] * f[e] + be[e] * r[e] + de[e];
-                    fb[j] = pack8(f);
-                    const long m = c_tile * 32 + j * 16 + fr;
-                    if (p.a_out && slice == 0 && m < M) *reinterpret_cast<bf16x8*>(p.a_out + m * p.lda_out + k) = fb[j];
-                }
-            }
-            if (has_affine || GATE) {
-                float s[8], b[8];
-                if (has_affine) { load8f(sc_s + k, s); load8f(sh_s + k, b); }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float f[8];
-                    unpack8(fb[j], f);
-                    if (has_affine) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = f[e] * s[e] + b[e];
-                        if (p.a_relu) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-                        }
-                    }
-                    if (GATE) {
-                        float g[8];
-                        load8f(c_gate[j] + k, g);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] *= g[e];
-                    }
-                    fb[j] = pack8(f);
-                }
-            }
-            // refill two slots at a time: consecutive k-steps are the two halves of the same 128-byte lines of A, and issued
-            // back to back the second load finds the line in (or on its way to) the vector L1 instead of fetching it again
-            if (d & 1) { fetch(d - 1); fetch(d); }
-            // ---- MFMA: D[n][m] += W[n][k] A[m][k]
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + (i * 16 + fr) * RS + k * 2);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fb[0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fb[1], acc[i][1], 0, 0, 0);
-            }
-            if (++c_ks < nk) continue;
-            // ---- tile done: bias / activation in registers, then through the staging buffer, 16 rows at a time
-            c_ks = 0;
-            const long m_base = c_tile * 32;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int nb = n0 + i * 16 + fq * 4;
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][r] * out_scale + (p.bias ? p.bias[nb + r] : 0.f);
-                        if (p.act == 1) v = fmaxf(v, 0.f);
-                        else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
-                        o[r] = (bf16)v;
-                    }
-                    *reinterpret_cast<bf16x4*>(stage + fr * SRS + (i * 16 + fq * 4) * 2) = o;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (o_active) {
-                    const int col = n0 + o_chunk * 8;
-#pragma unroll
-                    for (int rr = 0; rr < (16 + RPP - 1) / RPP; ++rr) {
-                        const int row = rr * RPP + o_rsub;
-                        const long m = m_base + j * 16 + row;
-                        if (row < 16 && m < M) {
-                            bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * SRS + o_chunk * 16);
-                            if (p.relu_mask) {
-                                const bf16x8 mk = *reinterpret_cast<const bf16x8*>((const bf16*)p.relu_mask + m * p.ldmask + col);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (!((float)mk[e] > 0.f)) v[e] = (bf16)0.f;
-                            }
-                            bf16* dst = (col < p.n_split) ? (bf16*)p.C0 + m * p.ldc0 + col : (bf16*)p.C + m * p.ldc + col;
-                            *reinterpret_cast<bf16x8*>(dst) = v;
-                            if (stats) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ssum[e] += f; ssq[e] += f * f; }
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            c_tile += tstride;
-            c_rows();
-        }
-    }
-    if (stats) {
-        if (o_active) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(&red[o_chunk * 8 + e], ssum[e]); atomicAdd(&red[NB + o_chunk * 8 + e], ssq[e]); }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * NB; t += WAVES * 64) {
-            const int which = t / NB, nl = t - which * NB;
-            atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[t]);
         }
     }
 }
@@ -836,28 +579,6 @@ static size_t wgrad_lds_bytes() {
     return (size_t)4 * (T == 128 ? 64 : 32) * (T + 16) * sizeof(bf16) + T * sizeof(float);
 }
 
-// Workgroups of one streaming-GEMM instantiation resident per CU at a given dynamic LDS size (cached: queried once per size).
-template <int NI, int WAVES, int PRO>
-static int stream_residency(size_t lds) {
-    static std::mutex mu;                          // entry points may be called from any host thread (autograd runs backward on its own)
-    std::lock_guard<std::mutex> lock(mu);
-    static bool attr_done = false;
-    static size_t seen[8];
-    static int val[8];
-    static int n_seen = 0;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, PRO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    for (int i = 0; i < n_seen; ++i) if (seen[i] == lds) return val[i];
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_kernel<NI, WAVES, PRO>, WAVES * 64, lds) != hipSuccess || per_cu < 1)
-        per_cu = 1;
-    if (n_seen < 8) { seen[n_seen] = lds; val[n_seen] = per_cu; ++n_seen; }
-    return per_cu;
-}
-
 }  // namespace
 
 extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
@@ -877,48 +598,17 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
                         (!a->a_out || (a->lda_out % 8 == 0 && a->lda_out >= a->K))),
                STES_ERR_ARG, "stes_gemm: the BatchNorm-backward prologue needs alpha/beta/delta and excludes the other prologues");
     STES_CHECK(bnb || !a->a_out, STES_ERR_ARG, "stes_gemm: a_out without a_raw");
+    // tall-and-skinny bf16 layers with small K and N: weights resident in LDS, rows streamed (stes_gemm_stream.hip)
+    if (stes_gemm_stream(a, stream)) {
+        STES_LAUNCH_CHECK();
+        return STES_OK;
+    }
     RowDivs dv;
     dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
     dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
     dv.gate = make_fastdiv(a->a_gate ? a->gate_group : 1);
-    // tall-and-skinny bf16 layers with small K and N: weights resident in LDS, rows streamed (gemm_stream_kernel)
-    {
-        int nb = 0;
-        if (a->N == 32 || a->N == 64 || a->N == 128 || a->N == 160) nb = a->N;
-        else if (a->N == 320) nb = 160;
-        else if (a->N % 128 == 0 && a->N <= 1024) nb = 128;     // wide layers with a short K (stage 4's first 1x1 conv): 128-column slices
-        const bool fits = nb > 0 && a->K % 32 == 0 && a->K <= 320 && !a->c_f32 && a->M >= 8192 && a->ldc % 8 == 0 &&
-                          (a->k0 == 0 || a->k0 % 8 == 0) && (a->n_split == 0 || (a->n_split % 8 == 0 && a->ldc0 % 8 == 0)) &&
-                          (!a->relu_mask || a->ldmask % 8 == 0) && (!a->a_gate || (nb >= 64 && a->K % 8 == 0 && a->gate_group >= 32 && a->K <= 4 * nb + 32));
-        if (fits) {
-            const int ni = nb / 16, waves = nb >= 128 ? 8 : 4;
-            const size_t lds = (size_t)nb * (2 * a->K + 32) + (size_t)waves * 16 * (nb * 2 + 16) +
-                               (size_t)((bnb ? 3 : 2) * a->K + 2 * nb) * sizeof(float);
-            const int n_slices = a->N / nb;
-            const int row_tiles = stes_div_up(a->M, 32);
-            int per_cu = 1;
-#define STREAM_CASE(NI_, W_, G_)                                                                                                   \
-    do {                                                                                                                           \
-        per_cu = stream_residency<NI_, W_, G_>(lds);                                                                               \
-        int m_slots = stes_div_up(row_tiles, W_);                                                                                  \
-        const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;                                                 \
-        if (m_slots > cap) m_slots = cap;                                                                                          \
-        const int grid = stes_div_up(m_slots, 8) * n_slices * 8;                                                                   \
-        hipLaunchKernelGGL((gemm_stream_kernel<NI_, W_, G_>), dim3(grid), dim3(W_ * 64), lds, (hipStream_t)stream, *a, row_tiles,   \
-                           n_slices, m_slots, dv);                                                                                 \
-    } while (0)
-            const int pro = bnb ? 2 : (a->a_gate != nullptr ? 1 : 0);
-            if (ni == 2) { if (pro == 2) STREAM_CASE(2, 4, 2); else STREAM_CASE(2, 4, 0); }
-            else if (ni == 4) { if (pro == 2) STREAM_CASE(4, 4, 2); else if (pro == 1) STREAM_CASE(4, 4, 1); else STREAM_CASE(4, 4, 0); }
-            else if (ni == 8) { if (pro == 2) STREAM_CASE(8, 8, 2); else if (pro == 1) STREAM_CASE(8, 8, 1); else STREAM_CASE(8, 8, 0); }
-            else { if (pro == 2) STREAM_CASE(10, 8, 2); else if (pro == 1) STREAM_CASE(10, 8, 1); else STREAM_CASE(10, 8, 0); }
-#undef STREAM_CASE
-            STES_LAUNCH_CHECK();
-            return STES_OK;
-        }
-    }
     STES_CHECK(!bnb, STES_ERR_UNSUPPORTED, "stes_gemm: the BatchNorm-backward prologue exists for the streaming shapes only "
-                                           "(N in {32,64,128,160,320} or a multiple of 128 up to 1024, K % 32 == 0, K <= 320, M >= 8192, bf16 output); run stes_bn_bwd_apply first");
+                                           "(N in {32,64,128,160,320} or a multiple of 128 up to 1024, K in {64,128,320}, M >= 8192, bf16 output, no epilogue option); run stes_bn_bwd_apply first");
     // no prologue and at most 2^28 multiply-adds: the latency-bound small kernel
     if (!a->a_scale && !a->a_gate && a->k0 == 0 && a->map_stride <= 1 && !a->col_sum && a->n_split == 0 &&
         (double)a->M * a->N * a->K <= (double)(1L << 28) && a->M <= 16L * 65535) {

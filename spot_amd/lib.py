@@ -200,13 +200,13 @@ def _gemm_work(a, out_bytes):
 
 
 def gemm_streams(M, N, K):
-    """True when stes_gemm runs an [M,K] x [N,K]^T bf16 product on its streaming kernel (the rule in stes_gemm.hip), the
-    only one with the BatchNorm-backward prologue."""
-    return bool(_stream_slice(N)) and K % 32 == 0 and K <= 320 and M >= 8192
+    """True when stes_gemm runs a plain or BatchNorm-backward [M,K] x [N,K]^T bf16 product on its streaming kernel (the rule
+    in stes_gemm_stream.hip), the only one with the BatchNorm-backward prologue."""
+    return bool(_stream_slice(N)) and K in (64, 128, 320) and M >= 8192
 
 
 def _stream_slice(N):
-    """Columns per workgroup of the streaming GEMM for an N-column output, 0 if it does not take N (rule in stes_gemm.hip)."""
+    """Columns per workgroup of the streaming GEMM for an N-column output, 0 if it does not take N (rule in stes_gemm_stream.hip)."""
     if N in (32, 64, 128, 160):
         return N
     if N == 320:
@@ -214,13 +214,18 @@ def _stream_slice(N):
     return 128 if N % 128 == 0 and N <= 1024 else 0
 
 
+_RING = {320: (10, 1, 1), 128: (4, 1, 2), 64: (2, 2, 2), 32: (1, 4, 2)}       # K -> (k-steps, tiles in the ring, 16-row fragments)
+
+
 def _gemm_kernel(a):
-    """Which kernel stes_gemm dispatches to (the rule in stes_gemm.hip)."""
-    stream_ok = (_stream_slice(a.N) and a.K % 32 == 0 and a.K <= 320 and not a.c_f32 and a.M >= 8192
-                 and (not a.a_gate or (a.N >= 64 and a.gate_group >= 32)))
+    """Which kernel stes_gemm dispatches to (the rules in stes_gemm_stream.hip and stes_gemm.hip)."""
+    nb = _stream_slice(a.N)
+    pro = 2 if a.a_raw else (1 if a.a_scale else 0)
+    stream_ok = (nb and a.K in _RING and not (a.K == 32 and pro == 2) and not a.c_f32 and a.M >= 8192
+                 and not a.relu_mask and not a.bias and a.act == 0 and a.out_scale in (0.0, 1.0)
+                 and (not a.a_scale or 8 * a.K <= 16 * (nb * 2 + 16)) and (not a.a_gate or (a.a_scale and a.gate_group >= 32)))
     if stream_ok:
-        nb = _stream_slice(a.N)
-        return "gemm_stream_kernel<%d, %d, %d>" % (nb // 16, 8 if nb >= 128 else 4, 2 if a.a_raw else (1 if a.a_gate else 0))
+        return "gemm_stream_kernel<%d, %d, %d, %d, %d, %d>" % ((nb // 16, 8 if nb >= 128 else 4, pro) + _RING[a.K])
     if (not a.a_scale and not a.a_gate and a.k0 == 0 and a.map_stride <= 1 and not a.col_sum and a.n_split == 0
             and a.M * a.N * a.K <= (1 << 28) and a.M <= 16 * 65535):
         return "gemm_small_kernel"
