@@ -211,7 +211,16 @@ int stes_im2col_stem_u8(const uint8_t* x, uint16_t* patches, const float* mean, 
  *   stes_gsm_bwd_wgrad: dw [2][fold/2][27], db [2]  += (atomics)
  *   stes_gsm_dxbn     : gradient at the BatchNorm3d output, ReLU mask applied, bf16 [M][fold]
  *                       (then stes_bn_bwd_reduce / _finalize with D = dxbn, raw1 = Xc)
- *   stes_gsm_bwd_dx   : dXf = dG + gate*(dG[t-+1] - dG) + alpha*dxbn + beta*x + delta                      */
+ *   stes_gsm_bwd_dx   : dXf = dG + gate*(dG[t-+1] - dG) + alpha*dxbn + beta*x + delta
+ *   stes_gsm_forward  : gate AND G in one kernel (_GSM.forward :103-130 whole): the gate conv runs on MFMA (channels first,
+ *                       the 3x3 spatial taps as a gather sum in LDS), the shift follows in the same workgroup.  fold >= 32.
+ *   stes_gsm_bwd_conv : backward of the gate conv in one kernel: dxbn (as stes_gsm_dxbn), the conv3D weight/bias gradient
+ *                       (as stes_gsm_bwd_wgrad) and the BatchNorm3d-backward sums s_dy += sum dxbn, s_dyr += sum dxbn * x
+ *                       (as stes_bn_bwd_reduce on dxbn, Xc).  fold >= 32.  ws: NULL, or stes_gsm_bwd_conv_ws_floats(fold)
+ *                       floats that are ZERO on entry (they are zero again on return): the per-workgroup partial sums then go
+ *                       to STES_GSM_WS_REPLICAS copies and a second small launch adds them up -- a thousand workgroups adding
+ *                       into the same few KiB serialise in the memory-side atomic units (6x the kernel's time without ws).  */
+#define STES_GSM_WS_REPLICAS 64
 typedef struct { int32_t B, T, H, W, fold; } stes_gsm_geom;
 int stes_gsm_prep(const float* w3d, uint16_t* wt, int fold, void* stream);
 int stes_gsm_gate(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d,
@@ -226,6 +235,12 @@ int stes_gsm_dxbn(const float* dpre, const uint16_t* Xc, const float* scale, con
 int stes_gsm_bwd_dx(const uint16_t* dG, const uint16_t* Xc, const float* gate, const uint16_t* dxbn,
                     const float* alpha, const float* beta, const float* delta, uint16_t* dXf, const stes_gsm_geom* g,
                     void* stream);
+int stes_gsm_forward(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d,
+                     float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream);
+int stes_gsm_bwd_conv(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d,
+                      uint16_t* dxbn, float* s_dy, float* s_dyr, float* dw, float* db, float* ws, const stes_gsm_geom* g,
+                      void* stream);
+int stes_gsm_bwd_conv_ws_floats(int fold);
 /* per-column sum / sum of squares of X[:, :ncols] (atomics) and/or a compact copy [M][ncols] of that slice */
 int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* sum, float* sumsq, uint16_t* copy,
                    void* stream);

@@ -627,6 +627,463 @@ __global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ forward in one kernel (fold >= 32): gate conv on MFMA + shift
+// Workgroup = (row tile, frame t, clip).  The frame's output needs the gates of frames t (both groups), t+1 (group 0) and
+// t-1 (group 1).  Per group the conv3d is a product over channels first: Z[tap(kh,kw)][pos] = sum_{kt,c} w[kt,kh,kw,c] *
+// relu(bn(x[frame t'+kt-1][pos][c])), accumulated by MFMA over the three frames (A = positions x channels straight from
+// global memory in operand layout, BatchNorm + ReLU in registers; B = channels x 9 taps), for the two target frames t' of
+// the group at once (every fetched fragment feeds both).  Z goes to LDS tap-major with a one-pixel zero frame, and the gate
+// is the 9-term spatial gather sum of it.  The shift then runs over the tile's rows in whole 16-byte chunks.
+struct FwdTile {
+    int TH, ZPp;                       // rows per tile; padded positions of one Z plane: (TH + 2) * (W + 2), made odd
+    FastDiv fd_W, fd_nch;
+};
+
+template <int KS>   // 32-channel k-steps per group: ceil(half / 32)
+__global__ __launch_bounds__(256) void gsm_fwd_fused_kernel(const bf16* __restrict__ Xc, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const bf16* __restrict__ wt,
+                                                            const float* __restrict__ b3d, float* __restrict__ gate,
+                                                            bf16* __restrict__ G, Geom gm, FwdTile ft) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
+    const int W = gm.W, H = gm.H, T = gm.T, ZW = W + 2, TH = ft.TH, ZPp = ft.ZPp;
+    const int h0 = blockIdx.x * TH, t = blockIdx.y, b = blockIdx.z;
+    const int NP = TH * W, PH = (TH + 2) * W;
+    float* zbuf = reinterpret_cast<float*>(smem);         // [2 targets][16 taps][ZPp]
+    float* gl = zbuf + 32 * ZPp;                           // [group][target][NP]: gates of (t, g) and of the group's neighbour frame
+    float* sc_s = gl + 4 * NP;
+    float* sh_s = sc_s + fold;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    for (int i = tid; i < 32 * ZPp; i += 256) zbuf[i] = 0.f;
+    for (int i = tid; i < fold; i += 256) { sc_s[i] = scale[i]; sh_s[i] = shift[i]; }
+    __syncthreads();
+    const long plane = (long)H * W;
+    const bf16* clip = Xc + (long)b * T * plane * fold;
+    const int ntiles = (PH + 15) >> 4;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int tb = g == 0 ? t + 1 : t - 1;             // the group's second target frame
+        const bool has_b = tb >= 0 && tb < T;
+        const int f0 = t - 1 - g;                          // input frames f0 .. f0 + 3
+        bf16x8 wf[3][KS];                                  // B fragments: lane (fr = tap (kh,kw), fq): 8 channels of w[g][kt][tap]
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = ks * 32 + 8 * fq;
+                wf[kt][ks] = (fr < 9 && c0 + 8 <= half) ? *reinterpret_cast<const bf16x8*>(wt + (long)(g * 27 + kt * 9 + fr) * half + c0) : zero8();
+            }
+        const float bias = b3d[g];
+        // (no prefetch across tiles: the registers it takes cost residency, and with few tiles per wave what hides the
+        // loads' latency is the other workgroups of the CU)
+        for (int i = wave; i < ntiles; i += 4) {
+            const int q = i * 16 + fr;                     // position of the tile with its halo rows: row h0 - 1 + q / W
+            uint32_t r, w;
+            fdivmod((uint32_t)q, ft.fd_W, r, w);
+            const int h = h0 - 1 + (int)r;
+            const bool pv = q < PH && h >= 0 && h < H;
+            const long off = pv ? ((long)h * W + (long)w) * fold + g * half : 0;
+            bf16x8 raw[4][KS];
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                int f = f0 + fi;
+                f = f < 0 ? 0 : (f >= T ? T - 1 : f);      // (frames outside the clip: a valid address, the value is not used)
+                const bf16* base = clip + (long)f * plane * fold + off;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int c0 = ks * 32 + 8 * fq;
+                    raw[fi][ks] = (pv && c0 + 8 <= half) ? *reinterpret_cast<const bf16x8*>(base + c0) : zero8();
+                }
+            }
+            f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int f = f0 + fi;
+                const int kta = fi - g, ktb = fi - 1 + g;  // temporal tap of frame f for target t and for target tb
+                if (f < 0 || f >= T) continue;             // zero padding in time (wave-uniform)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int c0 = ks * 32 + 8 * fq;
+                    bf16x8 v = zero8();
+                    if (pv && c0 + 8 <= half) {
+                        float fv[8];
+                        unpack8(raw[fi][ks], fv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) fv[e] = fmaxf(fv[e] * sc_s[g * half + c0 + e] + sh_s[g * half + c0 + e], 0.f);
+                        v = pack8(fv);
+                    }
+                    if (kta >= 0 && kta < 3) acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, wf[kta < 0 ? 0 : (kta > 2 ? 2 : kta)][ks], acc_a, 0, 0, 0);
+                    if (ktb >= 0 && ktb < 3 && has_b) acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, wf[ktb < 0 ? 0 : (ktb > 2 ? 2 : ktb)][ks], acc_b, 0, 0, 0);
+                }
+            }
+            // D[pos = 4 fq + e][tap = fr]
+            if (fr < 9) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = i * 16 + 4 * fq + e;
+                    if (qq < PH) {
+                        uint32_t rr, ww;
+                        fdivmod((uint32_t)qq, ft.fd_W, rr, ww);
+                        const int zp = (int)rr * ZW + (int)ww + 1;
+                        zbuf[fr * ZPp + zp] = acc_a[e];
+                        zbuf[(16 + fr) * ZPp + zp] = acc_b[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p < NP; p += 256) {
+            uint32_t r, w;
+            fdivmod((uint32_t)p, ft.fd_W, r, w);
+            const int zc = ((int)r + 1) * ZW + (int)w + 1;
+            float pa = bias, pb = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int o = zc + (kh - 1) * ZW + (kw - 1);
+                    pa += zbuf[(kh * 3 + kw) * ZPp + o];
+                    pb += zbuf[(16 + kh * 3 + kw) * ZPp + o];
+                }
+            gl[(g * 2) * NP + p] = tanhf(pa);
+            gl[(g * 2 + 1) * NP + p] = tanhf(pb);
+        }
+        __syncthreads();
+    }
+    // shift: G[m,c] = y[t+1 | t-1] + (x - y), y = gate * x (same operation order as gsm_shift_kernel)
+    const int items = NP * nch;
+    for (int it0 = 0; it0 < items; it0 += 1024) {         // four items per thread, their loads issued together
+        long mrow[4]; int pp[4], cc0[4]; bool ok[4];
+        bf16x8 xv4[4], xn4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u * 256 + tid;
+            uint32_t p, ch, r, w;
+            fdivmod((uint32_t)(it < items ? it : 0), ft.fd_nch, p, ch);
+            fdivmod(p, ft.fd_W, r, w);
+            const int h = h0 + (int)r;
+            ok[u] = it < items && h < H;
+            pp[u] = (int)p; cc0[u] = (int)ch * 8;
+            const long m = ((long)b * T + t) * plane + (long)(ok[u] ? h : h0) * W + (long)w;
+            mrow[u] = m;
+            const int g = cc0[u] >= half;
+            const int tn = g == 0 ? t + 1 : t - 1;
+            const bool has = tn >= 0 && tn < T;
+            xv4[u] = *reinterpret_cast<const bf16x8*>(Xc + m * fold + cc0[u]);
+            xn4[u] = *reinterpret_cast<const bf16x8*>(Xc + (has ? (g == 0 ? m + plane : m - plane) : m) * fold + cc0[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const int g = cc0[u] >= half, p = pp[u];
+            const int tn = g == 0 ? t + 1 : t - 1;
+            const bool has = tn >= 0 && tn < T;
+            const float gt = gl[(g * 2) * NP + p];
+            const float gn = has ? gl[(g * 2 + 1) * NP + p] : 0.f;
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xv = (float)xv4[u][k];
+                const float y = gt * xv;
+                const float rr = xv - y;
+                const float ys = has ? gn * (float)xn4[u][k] : 0.f;
+                o[k] = (bf16)(ys + rr);
+            }
+            *reinterpret_cast<bf16x8*>(G + mrow[u] * fold + cc0[u]) = o;
+            if (cc0[u] == 0) { gate[mrow[u] * 2] = gl[p]; gate[mrow[u] * 2 + 1] = gl[2 * NP + p]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward of the gate conv in one kernel (fold >= 32)
+// Workgroup = (row tile, frame, clip).  From the gate-gradient halo tile (3 frames, one-pixel frame, both groups) it builds
+// the im2col matrix Ag[pos][tap] = dpre[pos - off(tap), g] once per group in LDS (bf16) and uses it twice on MFMA:
+//   dw[g][c][tap] += sum_pos relu(bn(x[pos,c])) * Ag[pos,tap]   (reduction over positions: both operands read transposed),
+//   dxb[c][pos]    = sum_tap w[g][c][tap] * Ag[pos,tap]          (masked with bn(x) > 0, rounded to bf16 = dxbn),
+// and accumulates the BatchNorm3d-backward sums (sum dxbn, sum dxbn * x) of the values it writes.  The x tile sits in LDS
+// with rows permuted for conflict-free transposed reads; dxbn overwrites it in place and leaves as whole rows.
+// sum over the 16 lanes of a DPP row (lanes with the same lane >> 4); the total lands in the row's last lane.  Row shifts run
+// in the VALU: the LDS-crossbar shuffles (ds_bpermute) cost a hundred cycles per dependent step.
+__device__ __forceinline__ float row_sum_to_last(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int prow(int p) { return (p & ~31) | rho32(p & 31); }
+struct BwdTile {
+    int TH, NPp, SX;                   // rows per tile; positions rounded up to 32; x tile row stride (bytes)
+    FastDiv fd_W, fd_nch;
+};
+
+template <int NCT>   // 16-channel tiles per group: ceil(half / 16)
+__global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ w3d, bf16* __restrict__ dxbn,
+                                                           float* __restrict__ s_dy, float* __restrict__ s_dyr,
+                                                           float* __restrict__ dw, float* __restrict__ db, float* __restrict__ ws,
+                                                           int n_rep, Geom gm, BwdTile bt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SA = 96;                                 // Ag row stride (bytes): 32 taps + 16 pad, an odd multiple of 32
+    const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
+    const int W = gm.W, H = gm.H, T = gm.T, ZW = W + 2, TH = bt.TH, rows = TH + 2, NPp = bt.NPp, SX = bt.SX;
+    const int h0 = blockIdx.x * TH, t = blockIdx.y, b = blockIdx.z;
+    const int NP = TH * W;
+    unsigned char* xt = smem;                                                  // [NPp][SX] (+64 slack)
+    unsigned char* ag = xt + (size_t)NPp * SX + 64;                            // [NPp][SA]
+    unsigned char* wsm = ag + (size_t)NPp * SA;                                // [fold][32 taps] bf16: conv weights, zero-padded
+    float* dt = reinterpret_cast<float*>(wsm + (size_t)fold * 64);             // [3][rows][ZW][2]
+    float* red = dt + 3 * rows * ZW * 2;                                       // [fold][27]
+    float* sums = red + fold * 27;                                             // [2][fold]
+    float* dbs = sums + 2 * fold;                                              // [2]
+    float* sc_s = dbs + 2;                                                     // [fold]
+    float* sh_s = sc_s + fold;                                                 // [fold]
+    float* slab = sh_s + fold;                                                 // [4 waves][2][fold]: BatchNorm-backward partial sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const long plane = (long)H * W;
+    const long m0 = ((long)b * T + t) * plane;
+
+    // ---- stage.  Under load a dependent global load costs microseconds, so everything the workgroup reads leaves in ONE
+    // batch up front (x tile, gate-gradient halo, conv weights, BatchNorm constants); the phases below touch LDS only.
+    constexpr int XB = 8, DB = 4, WB = 6;                  // loads per thread in the first batch of each kind
+    const int n_x = NP * nch, n_d = 3 * rows * ZW, n_w = fold * 27 / 4;
+    auto x_src = [&](int i, int& dst) -> const bf16* {    // chunk i of the tile's rows: source address, LDS offset (-1: none)
+        uint32_t p, ch, r, w;
+        fdivmod((uint32_t)(i < n_x ? i : 0), bt.fd_nch, p, ch);
+        fdivmod(p, bt.fd_W, r, w);
+        const bool ok = i < n_x && h0 + (int)r < H;
+        dst = i < n_x ? prow((int)p) * SX + (int)ch * 16 : -1;
+        return ok ? Xc + (m0 + (long)(h0 + (int)r) * W + (long)w) * fold + ch * 8 : nullptr;
+    };
+    auto d_src = [&](int i) -> const float* {             // cell i of the halo tile (nullptr: zero padding)
+        const int wp = i % ZW; const int r2 = i / ZW;
+        const int hr = r2 % rows, kt = r2 / rows;
+        const int tt = t + kt - 1, hh = h0 + hr - 1, ww = wp - 1;
+        return (i < n_d && tt >= 0 && tt < T && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                   ? dpre + (((long)b * T + tt) * plane + (long)hh * W + ww) * 2 : nullptr;
+    };
+    auto w_put = [&](int i, const f32x4& v) {             // four consecutive floats of w3d [fold][27] -> bf16 [fold][32]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = i * 4 + e, c = k / 27, tap = k - c * 27;
+            reinterpret_cast<bf16*>(wsm)[c * 32 + tap] = (bf16)v[e];
+        }
+    };
+    {
+        bf16x8 xv[XB]; int xd[XB];
+        float2 dv[DB];
+        f32x4 wv[WB];
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const bf16* src = x_src(u * 256 + tid, xd[u]);
+            xv[u] = *reinterpret_cast<const bf16x8*>(src ? src : Xc);
+            if (!src) xv[u] = zero8();
+        }
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const float* src = d_src(u * 256 + tid);
+            dv[u] = *reinterpret_cast<const float2*>(src ? src : dpre);
+            if (!src) dv[u] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int i = u * 256 + tid;
+            wv[u] = *reinterpret_cast<const f32x4*>(w3d + 4 * (i < n_w ? i : 0));
+        }
+        const float scv = tid < fold ? scale[tid] : 0.f, shv = tid < fold ? shift[tid] : 0.f;
+        // (LDS that the loads do not fill: zero rows past the tile, weight padding, accumulators)
+        for (int i = tid; i < (NPp - NP) * (SX / 16); i += 256) {
+            const int pr = i / (SX / 16), chunk = i - pr * (SX / 16);
+            *reinterpret_cast<bf16x8*>(xt + (size_t)prow(NP + pr) * SX + (size_t)chunk * 16) = zero8();
+        }
+        for (int i = tid; i < NPp * (SA / 16); i += 256) *reinterpret_cast<bf16x8*>(ag + (size_t)i * 16) = zero8();
+        for (int i = tid; i < fold * 4; i += 256) *reinterpret_cast<bf16x8*>(wsm + (size_t)i * 16) = zero8();
+        for (int i = tid; i < fold * 27 + 2 * fold + 2; i += 256) red[i] = 0.f;  // red, sums and dbs are adjacent
+        __syncthreads();                                   // (the weight rows are zeroed before their 27 taps arrive)
+#pragma unroll
+        for (int u = 0; u < XB; ++u) if (xd[u] >= 0) *reinterpret_cast<bf16x8*>(xt + xd[u]) = xv[u];
+#pragma unroll
+        for (int u = 0; u < DB; ++u) if (u * 256 + tid < n_d) *reinterpret_cast<float2*>(dt + 2 * (u * 256 + tid)) = dv[u];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) if (u * 256 + tid < n_w) w_put(u * 256 + tid, wv[u]);
+        if (tid < fold) { sc_s[tid] = scv; sh_s[tid] = shv; }
+        // what the first batch did not cover (larger tiles or wider slices than the benchmarked ones)
+        for (int i = XB * 256 + tid; i < n_x; i += 256) {
+            int dst; const bf16* src = x_src(i, dst);
+            *reinterpret_cast<bf16x8*>(xt + dst) = src ? *reinterpret_cast<const bf16x8*>(src) : zero8();
+        }
+        for (int i = DB * 256 + tid; i < n_d; i += 256) {
+            const float* src = d_src(i);
+            *reinterpret_cast<float2*>(dt + 2 * i) = src ? *reinterpret_cast<const float2*>(src) : make_float2(0.f, 0.f);
+        }
+        for (int i = WB * 256 + tid; i < n_w; i += 256) w_put(i, *reinterpret_cast<const f32x4*>(w3d + 4 * i));
+    }
+    __syncthreads();
+
+    // this lane's eight taps 8 fq .. 8 fq + 7 as offsets into the halo tile relative to a position's own cell
+    int toff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int tap = 8 * fq + k;
+        const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        toff[k] = tap < 27 ? ((2 - kt) * rows + (1 - kh)) * ZW + (1 - kw) : -1000000;
+    }
+    const int r_lo = rho32(8 * fq + (fr >> 2)), r_hi = rho32(8 * fq + (fr >> 2) + 4);
+    const int cc = 4 * (fr & 3);
+    const int ptiles = (NP + 15) >> 4;
+
+#pragma unroll 1
+    for (int g = 0; g < 2; ++g) {
+        // ---- (a) Ag for this group: lane (fr = position, fq): taps 8 fq .. 8 fq + 7 -> one 16-byte chunk of the row
+        float bsum = 0.f;
+        for (int i = wave; i < ptiles; i += 4) {
+            const int p = i * 16 + fr;
+            uint32_t r, w;
+            fdivmod((uint32_t)p, bt.fd_W, r, w);
+            const bool pv = p < NP && h0 + (int)r < H;
+            const int zb = ((int)r + 1) * ZW + (int)w + 1;
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = (pv && toff[k] > -1000000) ? dt[2 * (zb + toff[k]) + g] : 0.f;
+            *reinterpret_cast<bf16x8*>(ag + (size_t)prow(p) * SA + fq * 16) = pack8(f);
+            if (fq == 1) bsum += f[5];                      // tap 13, the centre: the position's own gate gradient (conv bias gradient)
+        }
+        bsum = wave_sum(bsum);
+        if (lane == 0) atomicAdd(&dbs[g], bsum);
+        __syncthreads();
+        // ---- (b) conv weight gradient: a wave owns whole output tiles D[16 channels][16 taps] and walks every 32-position
+        // step itself, so the result needs no reduction between waves (LDS float atomics cost ~2 cycles per lane)
+        for (int ot = wave; ot < 2 * NCT; ot += 4) {
+            const int j = ot >> 1, n2 = ot & 1;
+            const int c = j * 16 + fr;
+            const bool cv = c < half;                      // (columns past the group hold other data: select, do not multiply)
+            const float sca = cv ? sc_s[g * half + c] : 0.f, sha = cv ? sh_s[g * half + c] : 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < (NPp >> 5); ++s) {
+                const unsigned char* xs = xt + (size_t)(s * 32) * SX + (g * half + j * 16 + cc) * 2;
+                const unsigned char* as = ag + (size_t)(s * 32) * SA + (n2 * 16 + cc) * 2;
+                const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(as + r_lo * SA));
+                const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(as + r_hi * SA));
+                const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xs + r_lo * SX));
+                const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xs + r_hi * SX));
+                float f[8];
+                unpack8(__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7), f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[k] = cv ? fmaxf(f[k] * sca + sha, 0.f) : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack8(f), __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7), acc, 0, 0, 0);
+            }
+            // D[c = 4 fq + e][tap = fr]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c4 = j * 16 + 4 * fq + e, tap = n2 * 16 + fr;
+                if (c4 < half && tap < 27) red[(g * half + c4) * 27 + tap] = acc[e];
+            }
+        }
+        __syncthreads();                                   // every wave is done reading this group's columns of the x tile
+        // ---- (c) dxb[c][pos] = sum_tap w[c][tap] Ag[pos][tap], masked and rounded, in place of x; BatchNorm-backward sums
+        {
+            bf16x8 wfr[NCT];
+            float scc[NCT][4], shc[NCT][4], s1[NCT][4], s2[NCT][4];
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) {
+                const int c = j * 16 + fr;
+                wfr[j] = c < half ? *reinterpret_cast<const bf16x8*>(wsm + (size_t)(g * half + c) * 64 + fq * 16) : zero8();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c4 = j * 16 + 4 * fq + e;
+                    scc[j][e] = c4 < half ? sc_s[g * half + c4] : 0.f;
+                    shc[j][e] = c4 < half ? sh_s[g * half + c4] : 0.f;
+                    s1[j][e] = 0.f; s2[j][e] = 0.f;
+                }
+            }
+            for (int i = wave; i < ptiles; i += 4) {
+                const int p = i * 16 + fr;
+                uint32_t r, w;
+                fdivmod((uint32_t)p, bt.fd_W, r, w);
+                const bool pv = p < NP && h0 + (int)r < H;
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ag + (size_t)prow(p) * SA + fq * 16);
+#pragma unroll
+                for (int j = 0; j < NCT; ++j) {
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], fb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const int c4 = j * 16 + 4 * fq;
+                    if (pv && c4 < half) {
+                        bf16x4* cell = reinterpret_cast<bf16x4*>(xt + (size_t)prow(p) * SX + (g * half + c4) * 2);
+                        const bf16x4 x4 = *cell;
+                        bf16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xv = (float)x4[e];
+                            const bf16 o = (bf16)((xv * scc[j][e] + shc[j][e] > 0.f) ? d[e] : 0.f);
+                            o4[e] = o;
+                            s1[j][e] += (float)o;
+                            s2[j][e] += (float)o * xv;
+                        }
+                        *cell = o4;
+                    }
+                }
+            }
+            // the 16 lanes of a DPP row hold the same channels: sum over positions in the VALU, then this wave's partial sums
+            // go to its own LDS slab (plain stores)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a1 = row_sum_to_last(s1[j][e]), a2 = row_sum_to_last(s2[j][e]);
+                    const int c4 = j * 16 + 4 * fq + e;
+                    if (fr == 15 && c4 < half) { slab[(wave * 2) * fold + g * half + c4] = a1; slab[(wave * 2 + 1) * fold + g * half + c4] = a2; }
+                }
+        }
+        __syncthreads();                                   // Ag is rebuilt for the next group
+    }
+    for (int i = tid; i < 2 * fold; i += 256) sums[i] = (slab[i] + slab[2 * fold + i]) + (slab[4 * fold + i] + slab[6 * fold + i]);
+    __syncthreads();
+    // ---- results: dxbn rows, statistics, weight gradient
+    for (int i = tid; i < NP * nch; i += 256) {
+        uint32_t p, ch, r, w;
+        fdivmod((uint32_t)i, bt.fd_nch, p, ch);
+        fdivmod(p, bt.fd_W, r, w);
+        if (h0 + (int)r < H)
+            *reinterpret_cast<bf16x8*>(dxbn + (m0 + (long)(h0 + (int)r) * W + (long)w) * fold + ch * 8) =
+                *reinterpret_cast<const bf16x8*>(xt + (size_t)prow((int)p) * SX + ch * 16);
+    }
+    // weight gradient, statistics, bias gradient: [fold*27][fold][fold][2] as laid out in LDS.  With a workspace the adds go to
+    // one of its n_rep replicas (every workgroup adding to the same few KiB serialises in the memory-side atomic units) and
+    // gsm_bwd_fold_kernel adds the replicas up; without one they go to the results directly.
+    const int nws = fold * 27 + 2 * fold + 2;
+    if (ws) {
+        float* rep = ws + (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % n_rep * nws;
+        for (int i = tid; i < nws; i += 256) atomicAdd(rep + i, red[i]);
+    } else {
+        for (int i = tid; i < fold * 27; i += 256) atomicAdd(dw + i, red[i]);
+        for (int i = tid; i < fold; i += 256) { atomicAdd(s_dy + i, sums[i]); atomicAdd(s_dyr + i, sums[fold + i]); }
+        if (tid < 2) atomicAdd(db + tid, dbs[tid]);
+    }
+}
+
+// adds the workspace replicas of gsm_bwd_conv_kernel to the results and leaves the workspace zero for the next call
+__global__ __launch_bounds__(256) void gsm_bwd_fold_kernel(float* __restrict__ ws, int n_rep, int fold, float* __restrict__ s_dy,
+                                                           float* __restrict__ s_dyr, float* __restrict__ dw, float* __restrict__ db) {
+    const int nws = fold * 27 + 2 * fold + 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nws) return;
+    float a = 0.f;
+    for (int r0 = 0; r0 < n_rep; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = r0 + k < n_rep ? ws[(size_t)(r0 + k) * nws + i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += v[k];
+            if (r0 + k < n_rep) ws[(size_t)(r0 + k) * nws + i] = 0.f;
+        }
+    }
+    if (i < fold * 27) dw[i] += a;
+    else if (i < fold * 27 + fold) s_dy[i - fold * 27] += a;
+    else if (i < fold * 27 + 2 * fold) s_dyr[i - fold * 27 - fold] += a;
+    else db[i - fold * 27 - 2 * fold] += a;
+}
+
 // ------------------------------------------------------------------ column statistics / slice copy of a strided tensor
 __global__ __launch_bounds__(256) void col_stats_kernel(const bf16* __restrict__ X, long ldx, int ncols, long M, float* sum, float* sumsq,
                                                         bf16* __restrict__ copy) {
@@ -889,5 +1346,82 @@ extern "C" int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C,
     hipLaunchKernelGGL(tsm_shift_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)X, (bf16*)out, fold, C, T, plane, M,
                        backward ? -1 : 1);
     STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+namespace {
+// rows per tile: about 256 positions, tiles of equal height
+int fused_tile_rows(const Geom& gm) {
+    const int thmax = gm.W >= 256 ? 1 : 256 / gm.W;
+    const int nt = stes_div_up(gm.H, thmax);
+    return stes_div_up(gm.H, nt);
+}
+}  // namespace
+
+extern "C" int stes_gsm_forward(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d,
+                                float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream) {
+    int rc = check_geom(g); if (rc) return rc;
+    STES_CHECK(Xc && scale && shift && wt && b3d && gate && G, STES_ERR_ARG, "stes_gsm_forward: null pointer");
+    STES_CHECK(g->fold >= 32, STES_ERR_UNSUPPORTED, "stes_gsm_forward: built for fold >= 32 (run stes_gsm_gate + stes_gsm_shift)");
+    const Geom gm = to_geom(g);
+    FwdTile ft;
+    ft.TH = fused_tile_rows(gm);
+    ft.ZPp = ((ft.TH + 2) * (gm.W + 2)) | 1;
+    ft.fd_W = make_fastdiv(gm.W); ft.fd_nch = make_fastdiv(gm.fold / 8);
+    const size_t lds = ((size_t)32 * ft.ZPp + 4 * ft.TH * gm.W + 2 * gm.fold) * sizeof(float);
+    STES_CHECK(lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_forward: image row too wide for the LDS tile");
+    const dim3 grid(stes_div_up(gm.H, ft.TH), gm.T, gm.B);
+    const int ks = (gm.fold / 2 + 31) / 32;
+#define FWD_CASE(K) hipLaunchKernelGGL((gsm_fwd_fused_kernel<K>), grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, (const bf16*)wt, b3d, gate, (bf16*)G, gm, ft)
+    if (ks == 1) FWD_CASE(1); else if (ks == 2) FWD_CASE(2); else FWD_CASE(3);
+#undef FWD_CASE
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_gsm_bwd_conv_ws_floats(int fold) { return STES_GSM_WS_REPLICAS * (fold * 27 + 2 * fold + 2); }
+
+extern "C" int stes_gsm_bwd_conv(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d,
+                                 uint16_t* dxbn, float* s_dy, float* s_dyr, float* dw, float* db, float* ws, const stes_gsm_geom* g,
+                                 void* stream) {
+    int rc = check_geom(g); if (rc) return rc;
+    STES_CHECK(dpre && Xc && scale && shift && w3d && dxbn && s_dy && s_dyr && dw && db, STES_ERR_ARG, "stes_gsm_bwd_conv: null pointer");
+    STES_CHECK(g->fold >= 32, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: built for fold >= 32 (run stes_gsm_dxbn, stes_gsm_bwd_wgrad, stes_bn_bwd_reduce)");
+    const Geom gm = to_geom(g);
+    BwdTile bt;
+    bt.TH = fused_tile_rows(gm);
+    const int np = bt.TH * gm.W;
+    bt.NPp = (np + 31) / 32 * 32;
+    bt.SX = ((gm.fold * 2 + 31) / 32 | 1) * 32;
+    bt.fd_W = make_fastdiv(gm.W); bt.fd_nch = make_fastdiv(gm.fold / 8);
+    const size_t lds = (size_t)bt.NPp * bt.SX + 64 + (size_t)bt.NPp * 96 + (size_t)gm.fold * 64 +
+                       ((size_t)3 * (bt.TH + 2) * (gm.W + 2) * 2 + gm.fold * 27 + 12 * gm.fold + 2) * sizeof(float);
+    STES_CHECK(lds <= 160 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: tile does not fit LDS");
+    const dim3 grid(stes_div_up(gm.H, bt.TH), gm.T, gm.B);
+    const int nct = (gm.fold / 2 + 15) / 16;
+#define BWD_CASE(N)                                                                                                                \
+    do {                                                                                                                           \
+        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&gsm_bwd_conv_kernel<N>),                    \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;     \
+        STES_CHECK(big_lds || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: cannot raise the dynamic LDS limit");    \
+        hipLaunchKernelGGL((gsm_bwd_conv_kernel<N>), grid, dim3(256), lds, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d,   \
+                           (bf16*)dxbn, s_dy, s_dyr, dw, db, ws, STES_GSM_WS_REPLICAS, gm, bt);                                    \
+    } while (0)
+    switch (nct) {
+        case 1: BWD_CASE(1); break;
+        case 2: BWD_CASE(2); break;
+        case 3: BWD_CASE(3); break;
+        case 4: BWD_CASE(4); break;
+        case 5: BWD_CASE(5); break;
+        default: BWD_CASE(6); break;
+    }
+#undef BWD_CASE
+    STES_LAUNCH_CHECK();
+    if (ws) {
+        const int nws = gm.fold * 27 + 2 * gm.fold + 2;
+        hipLaunchKernelGGL(gsm_bwd_fold_kernel, dim3(stes_div_up(nws, 256)), dim3(256), 0, S(stream), ws, STES_GSM_WS_REPLICAS, gm.fold,
+                           s_dy, s_dyr, dw, db);
+        STES_LAUNCH_CHECK();
+    }
     return STES_OK;
 }

@@ -158,9 +158,13 @@ class Block:
             geom = lib.gsm_geom(self.N // self.T, self.T, self.Hi, self.Wi, self.fold)
             self.geom = geom
             self.bng.finalize(Mi, train)
-            lib.call("stes_gsm_gate", p(self.Xc), p(self.bng.scale), p(self.bng.shift), p(self.wt), p(self.gsm.conv3D.bias), p(self.gate),
-                     C.byref(geom))
-            lib.call("stes_gsm_shift", p(self.Xc), p(self.gate), p(self.G), C.byref(geom))
+            if self.fold >= 80:          # gate conv (MFMA) and shift in one kernel (measured: faster from fold 80 up, slower at 32)
+                lib.call("stes_gsm_forward", p(self.Xc), p(self.bng.scale), p(self.bng.shift), p(self.wt), p(self.gsm.conv3D.bias),
+                         p(self.gate), p(self.G), C.byref(geom))
+            else:
+                lib.call("stes_gsm_gate", p(self.Xc), p(self.bng.scale), p(self.bng.shift), p(self.wt), p(self.gsm.conv3D.bias), p(self.gate),
+                         C.byref(geom))
+                lib.call("stes_gsm_shift", p(self.Xc), p(self.gate), p(self.G), C.byref(geom))
             a0, k0 = self.G, self.fold
         elif self.kind == "tsm":
             lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
@@ -278,11 +282,15 @@ class Block:
             gs, bng, geom, Xc, fold = self.gsm, self.bng, self.geom, self.Xc, self.fold
             dpre = sc("gsm.dpre", Mi * 2, F32)
             lib.call("stes_gsm_bwd_gate", p(dG), p(Xc), p(self.gate), p(dpre), C.byref(geom))
-            side(lambda: lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)),
-                                  p(g(gs.conv3D.bias)), C.byref(geom)))
             dxbn = sc("gsm.dxbn", Mi * fold)
-            lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), C.byref(geom))
-            lib.bn_bwd_reduce(dxbn, Xc, Mi, fold, [bng.s_dy, bng.s_dyr])
+            if fold >= 32:               # gate-conv backward in one kernel: dxbn, its BatchNorm3d sums, conv3D weight/bias gradient
+                lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), p(bng.s_dy),
+                         p(bng.s_dyr), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), p(e.gsm_ws(fold)), C.byref(geom))
+            else:
+                side(lambda: lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)),
+                                      p(g(gs.conv3D.bias)), C.byref(geom)))
+                lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), C.byref(geom))
+                lib.bn_bwd_reduce(dxbn, Xc, Mi, fold, [bng.s_dy, bng.s_dyr])
             bng.bwd_finalize(Mi)
             dXf = sc("gsm.dXf", Mi * fold)
             lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(self.gate), p(dxbn), p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
@@ -404,6 +412,14 @@ class Engine:
                 t.record_stream(self.side)       # the side stream may still be reading the tensor being replaced
             t = torch.empty(numel, dtype=dtype, device=self.dev)
             self._scratch[name] = t
+        return t
+
+    def gsm_ws(self, fold):
+        """Workspace of stes_gsm_bwd_conv: zero when first handed over, left zero by every call."""
+        n = lib.lib().stes_gsm_bwd_conv_ws_floats(fold)
+        t = self._scratch.get("gsm.ws")
+        if t is None or t.numel() < n:
+            t = self._scratch["gsm.ws"] = torch.zeros(n, device=self.dev)
         return t
 
     def scratch_pp(self, name, numel):

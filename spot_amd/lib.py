@@ -97,6 +97,8 @@ _SIGS = {
     "stes_gsm_bwd_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stes_gsm_dxbn": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stes_gsm_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stes_gsm_bwd_conv": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "stes_col_stats": [_P, _I64, _I32, _I64, _P, _P, _P, _P],
     "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gru_forward": [_P, _P],
@@ -110,7 +112,7 @@ _SIGS = {
     "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
-EXPORTS = ["stes_version", "stes_last_error"] + list(_SIGS)
+EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats"] + list(_SIGS)
 
 
 def lib():
@@ -122,6 +124,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.stes_last_error.restype = C.c_char_p
         L.stes_version.restype = C.c_int
+        L.stes_gsm_bwd_conv_ws_floats.argtypes = [C.c_int]
+        L.stes_gsm_bwd_conv_ws_floats.restype = C.c_int
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig

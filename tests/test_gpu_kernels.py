@@ -328,9 +328,10 @@ def test_block_in_grad_and_pool_bwd():
     close(out, ref, 1e-2, 1e-3)
 
 
-def _gsm_run(z, mode):
+def _gsm_run(z, mode, fused=False):
     """Run the GSM kernels on a golden case; returns y and the gradients in the reference's NCHW layout and channel order
-    (the kernels keep source channel order; dest(c) is the reference's within-group interleave)."""
+    (the kernels keep source channel order; dest(c) is the reference's within-group interleave).  fused: the one-kernel
+    forward (stes_gsm_forward) and the one-kernel gate-conv backward (stes_gsm_bwd_conv) in place of the kernel sequences."""
     from spot_amd import lib
     x = torch.from_numpy(z["x"]); gy = torch.from_numpy(z["gy"])
     NT, fold, H, W = x.shape
@@ -355,9 +356,13 @@ def _gsm_run(z, mode):
     wt = torch.empty(27 * fold, dtype=torch.bfloat16, device="cuda")
     lib.call("stes_gsm_prep", lib.ptr(w3d), lib.ptr(wt), fold)
     gate = torch.empty(M, 2, device="cuda")
-    lib.call("stes_gsm_gate", lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(wt), lib.ptr(b3d), lib.ptr(gate), C.byref(geom))
     G = torch.empty(M, fold, dtype=BF, device="cuda")
-    lib.call("stes_gsm_shift", lib.ptr(Xc), lib.ptr(gate), lib.ptr(G), C.byref(geom))
+    if fused:
+        lib.call("stes_gsm_forward", lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(wt), lib.ptr(b3d), lib.ptr(gate), lib.ptr(G),
+                 C.byref(geom))
+    else:
+        lib.call("stes_gsm_gate", lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(wt), lib.ptr(b3d), lib.ptr(gate), C.byref(geom))
+        lib.call("stes_gsm_shift", lib.ptr(Xc), lib.ptr(gate), lib.ptr(G), C.byref(geom))
     y = torch.empty(NT, fold, H, W)
     y[:, dest] = nchw(G.float().cpu(), NT, H, W)
     res = {"y": y, "rm": rm.cpu(), "rv": rv.cpu()}
@@ -366,11 +371,17 @@ def _gsm_run(z, mode):
         dpre = torch.empty(M, 2, device="cuda")
         lib.call("stes_gsm_bwd_gate", lib.ptr(dG), lib.ptr(Xc), lib.ptr(gate), lib.ptr(dpre), C.byref(geom))
         dw = torch.zeros_like(w3d); db = torch.zeros(2, device="cuda")
-        lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
         dxbn = torch.empty(M, fold, dtype=BF, device="cuda")
-        lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn), C.byref(geom))
         sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
-        lib.bn_bwd_reduce(dxbn, Xc, M, fold, [sd, sdx])
+        if fused:
+            ws = torch.zeros(lib.lib().stes_gsm_bwd_conv_ws_floats(fold), device="cuda")
+            lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn),
+                     lib.ptr(sd), lib.ptr(sdx), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), C.byref(geom))
+            assert not bool(ws.any())
+        else:
+            lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
+            lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn), C.byref(geom))
+            lib.bn_bwd_reduce(dxbn, Xc, M, fold, [sd, sdx])
         coef = [torch.empty(fold, device="cuda") for _ in range(3)]
         dgam = torch.zeros(fold, device="cuda"); dbet = torch.zeros(fold, device="cuda")
         lib.call("stes_bn_bwd_finalize", lib.ptr(sd), lib.ptr(sdx), lib.ptr(mean), lib.ptr(inv), lib.ptr(gam), float(M),
@@ -407,14 +418,72 @@ def test_gsm_gate_tiling(B, T, H, W, fold):
     close(gate, ref, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("B,T,H,W,fold", [(1, 3, 30, 30, 32), (2, 9, 14, 14, 80), (1, 5, 7, 7, 192), (1, 4, 25, 13, 32), (1, 1, 14, 14, 80),
+                                          (1, 2, 5, 40, 48), (1, 3, 3, 100, 32)])
+def test_gsm_fused_forward_and_backward_conv(B, T, H, W, fold):
+    """stes_gsm_forward against conv3d + the shift formula (reference model/shift.py:103-130) on the same bf16-rounded
+    operands, and stes_gsm_bwd_conv against the kernel sequence it replaces, over ragged row tiles, single-frame clips, tile
+    rows that are not a multiple of 16 positions and every channel-tile count."""
+    from spot_amd import lib
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + T + H + W + fold)
+    half, M = fold // 2, B * T * H * W
+    Xc = torch.randn(M, fold, generator=g).to(BF)
+    sc, sh = torch.rand(fold, generator=g) + 0.5, torch.randn(fold, generator=g) * 0.3
+    w3d = torch.randn(2, half, 3, 3, 3, generator=g) / (27 * half) ** 0.5
+    b3d = torch.randn(2, generator=g) * 0.1
+    wt = torch.empty(27 * fold, dtype=BF, device="cuda")
+    lib.call("stes_gsm_prep", lib.ptr(dev(w3d)), lib.ptr(wt), fold)
+    gate = torch.full((M, 2), 9.0, device="cuda")
+    G = torch.full((M, fold), 9.0, dtype=BF, device="cuda")
+    geom = lib.gsm_geom(B, T, H, W, fold)
+    dXc, dsc, dsh, dw3d, db3d = dev(Xc), dev(sc), dev(sh), dev(w3d), dev(b3d)
+    lib.call("stes_gsm_forward", lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(wt), lib.ptr(db3d), lib.ptr(gate), lib.ptr(G), C.byref(geom))
+    torch.cuda.synchronize()
+    xb = torch.relu(Xc.float() * sc + sh).to(BF).float().view(B, T, H, W, fold).permute(0, 4, 1, 2, 3)
+    ref = torch.tanh(F.conv3d(xb, w3d.to(BF).float(), b3d, padding=1, groups=2)).permute(0, 2, 3, 4, 1).reshape(M, 2)
+    close(gate, ref, 1e-4, 1e-4)
+    # the shift on the kernel's own gate values: bit-exact against the two-kernel path's shift
+    G2 = torch.empty_like(G)
+    lib.call("stes_gsm_shift", lib.ptr(dXc), lib.ptr(gate), lib.ptr(G2), C.byref(geom))
+    torch.cuda.synchronize()
+    assert torch.equal(G, G2)
+    # backward of the gate conv
+    dpre = dev(torch.randn(M, 2, generator=g) * 0.1)
+    outs = []
+    ws = torch.zeros(lib.lib().stes_gsm_bwd_conv_ws_floats(fold), device="cuda")
+    for fused in (0, 1, 2):                                   # the kernel sequence; fused with and without the workspace
+        dw = torch.zeros(2, half, 27, device="cuda"); db = torch.zeros(2, device="cuda")
+        dxbn = torch.full((M, fold), 9.0, dtype=BF, device="cuda")
+        sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
+        if fused:
+            lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw3d), lib.ptr(dxbn),
+                     lib.ptr(sd), lib.ptr(sdx), lib.ptr(dw), lib.ptr(db), lib.ptr(ws) if fused == 1 else None, C.byref(geom))
+        else:
+            lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw), lib.ptr(db), C.byref(geom))
+            lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw3d), lib.ptr(dxbn), C.byref(geom))
+            lib.bn_bwd_reduce(dxbn, dXc, M, fold, [sd, sdx])
+        torch.cuda.synchronize()
+        outs.append((dxbn.float().cpu(), dw.cpu(), db.cpu(), sd.cpu(), sdx.cpu()))
+    # the fused kernel rounds the gate gradient and the conv weights to bf16 for MFMA: 2^-9 relative per product
+    assert not bool(ws.any())                                 # the workspace is handed back zeroed
+    for k in (1, 2):
+        for name, a, b_ in zip(("dxbn", "dw", "db", "s_dy", "s_dyr"), outs[k], outs[0]):
+            assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 8e-3, (name, k)
+
+
 @pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_gsm_vs_reference_golden(golden, fold, mode):
+@pytest.mark.parametrize("fused", [False, True])
+def test_gsm_vs_reference_golden(golden, fold, mode, fused):
     """Inputs of the golden vectors rounded to bf16 (the kernels' storage type); expected values are the
     reference's fp32 outputs -> tolerance 2 bf16 ulp + the input rounding + the gate conv weights rounded to bf16 (like
-    every other conv weight on the path; up to 2592 products per gate value at fold 192)."""
+    every other conv weight on the path; up to 2592 products per gate value at fold 192).  fused: the one-kernel forward and
+    gate-conv backward (built for fold >= 32)."""
+    if fused and fold < 32:
+        pytest.skip("the fused kernels are built for fold >= 32")
     z = golden(f"gsm_f{fold}_{mode}_rand")
-    r = _gsm_run(z, mode)
+    r = _gsm_run(z, mode, fused)
     close(r["y"], torch.from_numpy(z["y"]), 2e-2, 5e-2)
     assert float((r["y"] - torch.from_numpy(z["y"])).norm() / torch.from_numpy(z["y"]).norm()) < 6e-3
     if mode == "train":
@@ -426,11 +495,11 @@ def test_gsm_vs_reference_golden(golden, fold, mode):
             assert float((a - b).norm() / (b.norm() + 1e-6)) < 3e-2, k
 
 
-@pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
-def test_gsm_zero_gate_shift_indexing_bit_exact(golden, fold):
+@pytest.mark.parametrize("fold,fused", [(8, False), (16, False), (32, False), (80, False), (192, False), (32, True), (80, True), (192, True)])
+def test_gsm_zero_gate_shift_indexing_bit_exact(golden, fold, fused):
     """conv3D = 0 (the reference's init): output is exactly the within-group channel interleave of the bf16 input."""
     z = golden(f"gsm_f{fold}_eval_zero")
-    r = _gsm_run(z, "eval")
+    r = _gsm_run(z, "eval", fused)
     xb = torch.from_numpy(z["x"]).to(BF).float()
     yref = torch.from_numpy(z["y"])
     # reference output is a pure permutation of its input, so the bf16 version must be the same permutation of the bf16 input
