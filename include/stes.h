@@ -249,18 +249,23 @@ int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C, int B, int
 
 /* ---------------------------------------------------- temporal head, loss, optimiser ----
  * Bidirectional GRU layer (torch.nn.GRU inside GRUPrediction, reference model/modules.py:20-36).
- * gi = x W_ih^T + b_ih for both directions comes from stes_gemm ([B,T,2,3H] bf16).  forward runs
- * T launches; with `saved` != NULL it keeps what the backward needs.  backward runs T launches
- * and leaves dgi (for dW_ih, db_ih, dx) and dgh (for dW_hh, db_hh with hprev_bf).            */
+ * gi = x W_ih^T + b_ih for both directions comes from stes_gemm ([B,T,2,3H] bf16).  With `saved` != NULL forward keeps
+ * what the backward needs; backward leaves dgi (for dW_ih, db_ih, dx) and dgh (for dW_hh, db_hh with hprev_bf).
+ * hstate / dhstate are workspaces of ws_floats floats (0 means 4*B*H).  With at least stes_gru_ws_floats(B, H, backward)
+ * floats, B <= 16 and H <= 768 the whole recurrence is ONE launch: every workgroup keeps its W_hh rows in registers for
+ * all T steps and the hidden state travels between workgroups through the workspace (write-through stores, a step
+ * counter, no cache write-back); otherwise it is T launches.  Both forms give the same results bit for bit.     */
 typedef struct {
     const uint16_t* gi; const uint16_t* whh; const uint16_t* whhT; const float* bhh;
     uint16_t* y; float* hstate; float* saved; uint16_t* hprev_bf;
     const float* dy; int64_t ld_dy; const uint16_t* mask;
     uint16_t* dgi; uint16_t* dgh; float* dhstate;
     int32_t B, T, H;
+    int64_t ws_floats;
 } stes_gru_args;
 int stes_gru_forward(const stes_gru_args* a, void* stream);
 int stes_gru_backward(const stes_gru_args* a, void* stream);
+int64_t stes_gru_ws_floats(int B, int H, int backward);
 /* stes_gru_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as stes_gru_forward,
  * except that a->hstate is ignored (may be NULL): the fp32 hidden-state ping-pong buffer is a 1 MiB array inside the

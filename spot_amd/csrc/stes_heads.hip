@@ -14,6 +14,35 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Gate arithmetic of one (batch row, hidden unit), shared by the launch-per-step and the one-launch kernels.  Contraction
+// into fused multiply-adds is off here: left to the compiler it depends on the surrounding code, and the two forms of
+// the recurrence must round alike (they are tested to agree bit for bit).
+struct GruFwdOut { float r, z, n, hn, h; };
+__device__ __forceinline__ GruFwdOut gru_gate_fwd(float ir, float iz, float in, float gh_r, float gh_z, float gh_n, float bh_r, float bh_z,
+                                                  float bh_n, float hp) {
+#pragma clang fp contract(off)
+    GruFwdOut o;
+    o.hn = gh_n + bh_n;
+    o.r = sigmoidf_(ir + gh_r + bh_r);
+    o.z = sigmoidf_(iz + gh_z + bh_z);
+    o.n = tanhf(in + o.r * o.hn);
+    o.h = (1.f - o.z) * o.n + o.z * hp;
+    return o;
+}
+struct GruBwdOut { float dr, dz, dn, dnr, dh_next; };
+__device__ __forceinline__ GruBwdOut gru_gate_bwd(float dh, float rg, float zg, float ng, float hn, float hp) {
+#pragma clang fp contract(off)
+    GruBwdOut o;
+    const float dn = dh * (1.f - zg);
+    const float dz = dh * (hp - ng);
+    o.dn = dn * (1.f - ng * ng);
+    o.dr = o.dn * hn * rg * (1.f - rg);
+    o.dz = dz * zg * (1.f - zg);
+    o.dnr = o.dn * rg;
+    o.dh_next = dh * zg;
+    return o;
+}
+
 // ------------------------------------------------------------------ GRU forward step
 // grid (H/16, 2 dirs, batch tiles of 16); block 256
 __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const stes_gru_args p, int step) {
@@ -72,17 +101,141 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const stes_gru_args p
         const bf16* gi = (const bf16*)p.gi + (((long)b * T + t) * 2 + dir) * 3 * H;
         const float ir = (float)gi[j], iz = (float)gi[H + j], in = (float)gi[2 * H + j];
         const float hp = step > 0 ? p.hstate[(((long)dir * 2 + ((step - 1) & 1)) * B + b) * H + j] : 0.f;
-        const float hn = gh[2] + bh_n;
-        const float rg = sigmoidf_(ir + gh[0] + bh_r);
-        const float zg = sigmoidf_(iz + gh[1] + bh_z);
-        const float ng = tanhf(in + rg * hn);
-        const float h = (1.f - zg) * ng + zg * hp;
+        const GruFwdOut go = gru_gate_fwd(ir, iz, in, gh[0], gh[1], gh[2], bh_r, bh_z, bh_n, hp);
+        const float hn = go.hn, rg = go.r, zg = go.z, ng = go.n, h = go.h;
         p.hstate[(((long)dir * 2 + (step & 1)) * B + b) * H + j] = h;
         ((bf16*)p.y)[((long)b * T + t) * 2 * H + dir * H + j] = (bf16)h;
         if (p.saved) {
             float* sv = p.saved + ((((long)dir * T + t) * B + b) * 5) * H;      // r, z, n, hn, hprev
             sv[j] = rg; sv[H + j] = zg; sv[2 * H + j] = ng; sv[3 * H + j] = hn; sv[4 * H + j] = hp;
             ((bf16*)p.hprev_bf)[(((long)dir * T + t) * B + b) * H + j] = (bf16)hp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GRU forward, the whole recurrence in ONE launch
+// grid (H/32, 2 dirs), 512 threads; B <= 16, H <= 768.  A workgroup owns 32 hidden units of one direction for all T steps:
+// its W_hh rows (3 gates x 32 units x H) stay in registers as MFMA B fragments (wave = unit half x quarter of the k-steps,
+// the k-step assignment and every sum in the order of gru_fwd_step_kernel, so the results are the same bit for bit), its
+// fp32 hidden state stays in registers too.  Between steps the workgroups of a direction exchange the new hidden state
+// (bf16, what the step kernel reads back from y) through a small global buffer without any cache write-back or
+// invalidate: a workgroup's 16 x 32 tile is exactly the A-operand tile of one k-step, written as ONE 1 KiB write-through
+// (sc1) store instruction of one wave, followed by that wave's vmcnt(0) wait and one agent-scope counter add; consumers
+// poll the counter with an sc1 load, pass a workgroup barrier and read the tiles with sc1 loads (L2-served).  Spins are
+// bounded.  hx: [dir][parity][H/32 tiles][16 rows][32 units] bf16, cnt: one counter per direction on its own line.
+constexpr int GRU_U = 6;                                       // k-steps per wave (H <= 768)
+__device__ __forceinline__ bf16x8 load_sc1(const void* ptr) {
+    bf16x8 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void store_sc1(void* ptr, bf16x8 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all workgroups of the direction have published step `step - 1` (each adds one per step)
+__device__ __forceinline__ void gru_wait(unsigned* cnt, unsigned target) {
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+}
+
+__global__ __launch_bounds__(512) void gru_fwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ hx) {
+    __shared__ float red[8][64][12];
+    __shared__ __attribute__((aligned(16))) bf16 tile[16 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int uh = wave >> 2, kq = wave & 3;               // unit half, k-step residue
+    const int blk = blockIdx.x, dir = blockIdx.y;
+    const int H = p.H, T = p.T, B = p.B, nk = H / 32;
+    const int j = blk * 32 + uh * 16 + fr;                 // B operand column / epilogue unit of this lane
+    const bf16* __restrict__ whh = (const bf16*)p.whh + (long)dir * 3 * H * H;
+    bf16x8 fb[GRU_U][3];
+#pragma unroll
+    for (int u = 0; u < GRU_U; ++u) {
+        const int ks = kq + 4 * u, k = ks * 32 + fq * 8;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) fb[u][g] = ks < nk ? *reinterpret_cast<const bf16x8*>(whh + ((long)g * H + j) * H + k) : zero8();
+    }
+    const bool epi = kq == 0;                              // waves 0 and 4 finish the gates of their unit half
+    const float* bhh = p.bhh + (long)dir * 3 * H;
+    const float bh_r = bhh[j], bh_z = bhh[H + j], bh_n = bhh[2 * H + j];
+    unsigned* my_cnt = cnt + dir * 32;
+    bf16* hx_dir = hx + (long)dir * 2 * nk * 512;
+    float hp[4] = {0.f, 0.f, 0.f, 0.f};
+    float gic[4][3];                                       // input projections of the current step, fetched a step ahead
+    auto load_gi = [&](int step, float (&dst)[4][3]) {
+        const int t = dir == 0 ? step : T - 1 - step;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = fq * 4 + r;
+            const uint32_t o = (uint32_t)((((b < B ? b : 0) * T + t) * 2 + dir) * 3 * H + j);      // (element counts < 2^31: checked by the host)
+            const bf16* gi = (const bf16*)p.gi;
+            dst[r][0] = (float)gi[o]; dst[r][1] = (float)gi[o + (uint32_t)H]; dst[r][2] = (float)gi[o + 2u * (uint32_t)H];
+        }
+    };
+    if (epi) load_gi(0, gic);
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (threadIdx.x == 0) gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step);
+            __syncthreads();
+            const bf16* src = hx_dir + (long)((step - 1) & 1) * nk * 512 + fr * 32 + fq * 8;
+            bf16x8 fa[GRU_U];
+#pragma unroll
+            for (int u = 0; u < GRU_U; ++u) {
+                const int ks = kq + 4 * u;
+                fa[u] = load_sc1(src + (long)(ks < nk ? ks : 0) * 512);
+            }
+            wait_vm0();
+#pragma unroll
+            for (int u = 0; u < GRU_U; ++u)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    if (kq + 4 * u < nk) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], fb[u][g], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][lane][g * 4 + r] = acc[g][r];
+        __syncthreads();
+        float rg[4], zg[4], ng[4], hn[4], hold[4];
+        if (epi) {
+            const int w0 = uh * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gh[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    gh[g] = red[w0][lane][g * 4 + r] + red[w0 + 1][lane][g * 4 + r] + red[w0 + 2][lane][g * 4 + r] + red[w0 + 3][lane][g * 4 + r];
+                hold[r] = hp[r];
+                const GruFwdOut go = gru_gate_fwd(gic[r][0], gic[r][1], gic[r][2], gh[0], gh[1], gh[2], bh_r, bh_z, bh_n, hold[r]);
+                hn[r] = go.hn; rg[r] = go.r; zg[r] = go.z; ng[r] = go.n;
+                const float h = go.h;
+                hp[r] = h;
+                tile[(fq * 4 + r) * 32 + uh * 16 + fr] = (fq * 4 + r < B) ? (bf16)h : (bf16)0.f;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                   // publish first: the other workgroups wait for this
+            store_sc1(hx_dir + (long)(step & 1) * nk * 512 + (long)blk * 512 + lane * 8, *reinterpret_cast<const bf16x8*>(tile + lane * 8));
+            wait_vm0();
+            if (lane == 0) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (epi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = fq * 4 + r;
+                if (b >= B) continue;
+                ((bf16*)p.y)[(uint32_t)((b * T + t) * 2 * H + dir * H + j)] = (bf16)hp[r];
+                if (p.saved) {
+                    const uint32_t o = (uint32_t)((((dir * T + t) * B + b) * 5) * H + j);             // r, z, n, hn, hprev
+                    const uint32_t Hu = (uint32_t)H;
+                    p.saved[o] = rg[r]; p.saved[o + Hu] = zg[r]; p.saved[o + 2 * Hu] = ng[r]; p.saved[o + 3 * Hu] = hn[r]; p.saved[o + 4 * Hu] = hold[r];
+                    ((bf16*)p.hprev_bf)[(uint32_t)(((dir * T + t) * B + b) * H + j)] = (bf16)hold[r];
+                }
+            }
+            if (step + 1 < T) load_gi(step + 1, gic);      // arrives while the next step waits for the other workgroups
         }
     }
 }
@@ -140,16 +293,127 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const stes_gru_args p
         dh += dy;
         const float* sv = p.saved + ((((long)dir * T + t) * B + b) * 5) * H;
         const float rg = sv[j], zg = sv[H + j], ng = sv[2 * H + j], hn = sv[3 * H + j], hp = sv[4 * H + j];
-        const float dn = dh * (1.f - zg);
-        const float dz = dh * (hp - ng);
-        const float dnp = dn * (1.f - ng * ng);
-        const float drp = dnp * hn * rg * (1.f - rg);
-        const float dzp = dz * zg * (1.f - zg);
-        p.dhstate[(((long)dir * 2 + (step & 1)) * B + b) * H + j] = dh * zg;
+        const GruBwdOut go = gru_gate_bwd(dh, rg, zg, ng, hn, hp);
+        p.dhstate[(((long)dir * 2 + (step & 1)) * B + b) * H + j] = go.dh_next;
         bf16* dgi = (bf16*)p.dgi + (((long)b * T + t) * 2 + dir) * 3 * H;
-        dgi[j] = (bf16)drp; dgi[H + j] = (bf16)dzp; dgi[2 * H + j] = (bf16)dnp;
+        dgi[j] = (bf16)go.dr; dgi[H + j] = (bf16)go.dz; dgi[2 * H + j] = (bf16)go.dn;
         bf16* dg = dgh_all + (((long)dir * T + t) * B + b) * 3 * H;
-        dg[j] = (bf16)drp; dg[H + j] = (bf16)dzp; dg[2 * H + j] = (bf16)(dnp * rg);
+        dg[j] = (bf16)go.dr; dg[H + j] = (bf16)go.dz; dg[2 * H + j] = (bf16)go.dnr;
+    }
+}
+
+// ------------------------------------------------------------------ GRU backward, the whole recurrence in ONE launch
+// The counterpart of gru_fwd_persist_kernel: a workgroup owns 32 hidden units of one direction, its W_hh^T rows (K = 3H)
+// stay in registers, dh stays in registers, and what travels between workgroups per step is the gate-gradient vector
+// (dr, dz, dn * r as bf16: three 16 x 32 tiles per workgroup, the A-operand tiles of k-steps g * H/32 + blk), by the same
+// write-through store / counter / sc1-load hand-off.  k-step assignment and summation order are gru_bwd_step_kernel's.
+constexpr int GRU_UB = 18;                                     // k-steps per wave: 3H / 32 / 4, H <= 768
+__global__ __launch_bounds__(512) void gru_bwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ dx) {
+    __shared__ float red[8][64][4];
+    __shared__ __attribute__((aligned(16))) bf16 tile[3][16 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int uh = wave >> 2, kq = wave & 3;
+    const int blk = blockIdx.x, dir = blockIdx.y;
+    const int H = p.H, T = p.T, B = p.B, K = 3 * H, nk = K / 32, nkh = H / 32;
+    const int j = blk * 32 + uh * 16 + fr;
+    const bf16* __restrict__ whhT = (const bf16*)p.whhT + (long)dir * 3 * H * H;   // [H][3H]
+    bf16x8 fb[GRU_UB];
+#pragma unroll
+    for (int v = 0; v < GRU_UB; ++v) {
+        const int ks = kq + 4 * v;
+        fb[v] = ks < nk ? *reinterpret_cast<const bf16x8*>(whhT + (long)j * K + ks * 32 + fq * 8) : zero8();
+    }
+    const bool epi = kq == 0;
+    unsigned* my_cnt = cnt + dir * 32;
+    bf16* dx_dir = dx + (long)dir * 2 * nk * 512;
+    bf16* dgh_all = (bf16*)p.dgh;                         // [2][T][B][3H]
+    float dhp[4] = {0.f, 0.f, 0.f, 0.f};
+    // what the gate math of a step reads, fetched a step ahead: r, z, n, hn, hprev, dy (masked)
+    float cur[4][6];
+    auto prefetch = [&](int step, float (&dst)[4][6]) {
+        const int s = T - 1 - step;
+        const int t = dir == 0 ? s : T - 1 - s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = fq * 4 + r < B ? fq * 4 + r : 0;
+            const uint32_t o = (uint32_t)((((dir * T + t) * B + b) * 5) * H + j), Hu = (uint32_t)H;   // (element counts < 2^31: checked by the host)
+            dst[r][0] = p.saved[o]; dst[r][1] = p.saved[o + Hu]; dst[r][2] = p.saved[o + 2 * Hu]; dst[r][3] = p.saved[o + 3 * Hu]; dst[r][4] = p.saved[o + 4 * Hu];
+            float dy = p.dy[(uint32_t)((b * T + t) * (int)p.ld_dy + dir * H + j)];
+            if (p.mask) dy *= (float)((const bf16*)p.mask)[(uint32_t)((b * T + t) * 2 * H + dir * H + j)];
+            dst[r][5] = dy;
+        }
+    };
+    if (epi) prefetch(0, cur);
+    for (int step = 0; step < T; ++step) {
+        const int s = T - 1 - step;
+        const int t = dir == 0 ? s : T - 1 - s;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (threadIdx.x == 0) gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step);
+            __syncthreads();
+            const bf16* src = dx_dir + (long)((step - 1) & 1) * nk * 512 + fr * 32 + fq * 8;
+            f32x4 part[3] = {acc, acc, acc};
+#pragma unroll
+            for (int half_ = 0; half_ < 2; ++half_) {      // two batches of nine tiles: all eighteen at once spill
+                bf16x8 fa[GRU_UB / 2];
+#pragma unroll
+                for (int w = 0; w < GRU_UB / 2; ++w) {
+                    const int ks = kq + 4 * (half_ * (GRU_UB / 2) + w);
+                    fa[w] = load_sc1(src + (long)(ks < nk ? ks : 0) * 512);
+                }
+                wait_vm0();
+#pragma unroll
+                for (int w = 0; w < GRU_UB / 2; ++w) {
+                    const int v = half_ * (GRU_UB / 2) + w;
+                    if (kq + 4 * v < nk) part[v % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[w], fb[v], part[v % 3], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = part[0][r] + part[1][r] + part[2][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+        __syncthreads();
+        float drp[4], dzp[4], dnp[4], dnr[4];
+        if (epi) {
+            const int w0 = uh * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dh = red[w0][lane][r] + red[w0 + 1][lane][r] + red[w0 + 2][lane][r] + red[w0 + 3][lane][r];
+                if (step > 0) dh += dhp[r];
+                dh += cur[r][5];
+                const GruBwdOut go = gru_gate_bwd(dh, cur[r][0], cur[r][1], cur[r][2], cur[r][3], cur[r][4]);
+                dnp[r] = go.dn; drp[r] = go.dr; dzp[r] = go.dz; dnr[r] = go.dnr;
+                dhp[r] = go.dh_next;
+                const bool on = fq * 4 + r < B;
+                const int o = (fq * 4 + r) * 32 + uh * 16 + fr;
+                tile[0][o] = on ? (bf16)drp[r] : (bf16)0.f;
+                tile[1][o] = on ? (bf16)dzp[r] : (bf16)0.f;
+                tile[2][o] = on ? (bf16)dnr[r] : (bf16)0.f;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                   // publish first: the other workgroups wait for this
+            bf16* dst = dx_dir + (long)(step & 1) * nk * 512 + lane * 8;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) store_sc1(dst + (long)(g * nkh + blk) * 512, *reinterpret_cast<const bf16x8*>(&tile[g][lane * 8]));
+            wait_vm0();
+            if (lane == 0) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (epi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = fq * 4 + r;
+                if (b >= B) continue;
+                const uint32_t Hu = (uint32_t)H;
+                const uint32_t oi = (uint32_t)((((b * T + t) * 2 + dir) * 3) * H + j), og = (uint32_t)((((dir * T + t) * B + b) * 3) * H + j);
+                bf16* dgi = (bf16*)p.dgi;
+                dgi[oi] = (bf16)drp[r]; dgi[oi + Hu] = (bf16)dzp[r]; dgi[oi + 2 * Hu] = (bf16)dnp[r];
+                dgh_all[og] = (bf16)drp[r]; dgh_all[og + Hu] = (bf16)dzp[r]; dgh_all[og + 2 * Hu] = (bf16)dnr[r];
+            }
+            if (step + 1 < T) prefetch(step + 1, cur);     // arrives while the next step waits for the other workgroups
+        }
     }
 }
 
@@ -348,13 +612,33 @@ static int gru_check(const stes_gru_args* a) {
     return STES_OK;
 }
 
+// floats of workspace the one-launch recurrence needs at hstate (forward) / dhstate (backward): a 256-byte counter block and
+// the exchange tiles [2 dirs][2 parities][k-steps][16][32] bf16
+static int64_t gru_persist_floats(int H, int backward) { return 64 + (int64_t)(backward ? 3 : 1) * 4 * (H / 32) * 256; }
+
+extern "C" int64_t stes_gru_ws_floats(int B, int H, int backward) {
+    const int64_t step = 4L * B * H, one = (B <= 16 && H <= 32 * 4 * GRU_U) ? gru_persist_floats(H, backward) : 0;
+    return step > one ? step : one;
+}
+
+// the forward recurrence on the caller's stream: one launch when the workspace allows it, else one launch per step
+static int gru_forward_launch(const stes_gru_args& a, int64_t ws_floats, hipStream_t stream) {
+    if (a.B <= 16 && a.H <= 32 * 4 * GRU_U && ws_floats >= gru_persist_floats(a.H, 0) && 2L * a.T * a.B * 6 * a.H < (1L << 31)) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(a.hstate);
+        if (hipMemsetAsync(cnt, 0, 256, stream) != hipSuccess) return stes_set_error(STES_ERR_LAUNCH, "stes_gru_forward: cannot clear the step counters");
+        hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(a.H / 32, 2), dim3(512), 0, stream, a, cnt, reinterpret_cast<bf16*>(a.hstate + 64));
+    } else {
+        const dim3 grid(a.H / 16, 2, stes_div_up(a.B, 16));
+        for (int s = 0; s < a.T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, a, s);
+    }
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
 extern "C" int stes_gru_forward(const stes_gru_args* a, void* stream) {
     int rc = gru_check(a); if (rc) return rc;
     STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward: saved needs hprev_bf");
-    const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
-    for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
-    STES_LAUNCH_CHECK();
-    return STES_OK;
+    return gru_forward_launch(*a, a->ws_floats, S(stream));
 }
 
 // ------------------------------------------------------------------ GRU forward for callers that cannot allocate
@@ -387,20 +671,25 @@ extern "C" int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream) {
         }
         ptr = g_scratch_ptr[dev];
     }
-    // nothing in the buffer has to start at zero: step 0 takes h = 0 without reading it, step s reads what step s-1 wrote
+    // what must start at zero (the step counters of the one-launch recurrence) is cleared by a memset node on the stream;
+    // the step launches need nothing cleared: step 0 takes h = 0 without reading the buffer, step s reads what step s-1 wrote
     stes_gru_args b = *a;
     b.hstate = ptr;
-    const dim3 grid(b.H / 16, 2, stes_div_up(b.B, 16));
-    for (int s = 0; s < b.T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, S(stream), b, s);
-    STES_LAUNCH_CHECK();
-    return STES_OK;
+    return gru_forward_launch(b, GRU_SCRATCH_FLOATS, S(stream));
 }
 
 extern "C" int stes_gru_backward(const stes_gru_args* a, void* stream) {
     int rc = gru_check(a); if (rc) return rc;
     STES_CHECK(a->saved && a->whhT && a->dy && a->dgi && a->dgh && a->dhstate && a->ld_dy >= 2 * a->H, STES_ERR_ARG, "stes_gru_backward: null pointer");
-    const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
-    for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
+    if (a->B <= 16 && a->H <= 32 * 4 * GRU_U && a->ws_floats >= gru_persist_floats(a->H, 1) && 2L * a->T * a->B * 6 * a->H < (1L << 31) &&
+        (long)a->B * a->T * a->ld_dy < (1L << 31)) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(a->dhstate);
+        STES_CHECK(hipMemsetAsync(cnt, 0, 256, S(stream)) == hipSuccess, STES_ERR_LAUNCH, "stes_gru_backward: cannot clear the step counters");
+        hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(a->H / 32, 2), dim3(512), 0, S(stream), *a, cnt, reinterpret_cast<bf16*>(a->dhstate + 64));
+    } else {
+        const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
+        for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);
+    }
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -622,7 +622,7 @@ class Engine:
                 Hh = L.H
                 L.gi = a(f"gru{i}.gi", N * 6 * Hh, BF)
                 L.y = a(f"gru{i}.y", N * 2 * Hh, BF)
-                L.hstate = a(f"gru{i}.hs", 4 * B * Hh, F32)
+                L.hstate = a(f"gru{i}.hs", lib.lib().stes_gru_ws_floats(B, Hh, 0), F32)     # large enough for the one-launch recurrence
                 L.saved = a(f"gru{i}.saved", 2 * T * B * 5 * Hh, F32) if train else None
                 L.hprev = a(f"gru{i}.hprev", 2 * T * B * Hh, BF) if train else None
             Hh = self.gru_layers[-1].H
@@ -719,7 +719,7 @@ class Engine:
             for L in self.gru_layers:
                 lib.gemm(xin, L.lin.w_bf, L.gi, N, 6 * L.H, in_dim, bias=L.bih_all)
                 a = lib.gru_args(gi=L.gi, whh=L.whh_bf, whhT=L.whhT_bf, bhh=L.bhh_all, y=L.y, hstate=L.hstate, saved=L.saved,
-                                 hprev_bf=L.hprev, B=B, T=T, H=L.H)
+                                 hprev_bf=L.hprev, B=B, T=T, H=L.H, ws_floats=L.hstate.numel())
                 lib.check(lib.lib().stes_gru_forward(C.byref(a), lib.stream()), "stes_gru_forward")
                 xin, in_dim = L.y, 2 * L.H
             self.fc_in = xin
@@ -798,9 +798,10 @@ class Engine:
                 L = self.gru_layers[li]
                 Hh = L.H
                 dgi, dgh = sc("gru.dgi", N * 6 * Hh), sc("gru.dgh", 2 * T * B * 3 * Hh)
-                dhs = sc("gru.dhs", 4 * B * Hh, F32)
+                dhs = sc("gru.dhs", lib.lib().stes_gru_ws_floats(B, Hh, 1), F32)
                 a = lib.gru_args(gi=L.gi, whh=L.whh_bf, whhT=L.whhT_bf, bhh=L.bhh_all, y=L.y, hstate=L.hstate, saved=L.saved,
-                                 hprev_bf=L.hprev, dy=dy, ld_dy=2 * Hh, mask=mask, dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=Hh)
+                                 hprev_bf=L.hprev, dy=dy, ld_dy=2 * Hh, mask=mask, dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=Hh,
+                                 ws_floats=dhs.numel())
                 lib.check(lib.lib().stes_gru_backward(C.byref(a), lib.stream()), "stes_gru_backward")
                 xin = self.feat_in if li == 0 else self.gru_layers[li - 1].y
                 lib.wgrad(dgi, xin, g(L.wih_all), N, 6 * Hh, L.I, dbias=g(L.bih_all))

@@ -66,7 +66,7 @@ GruArgs = _struct("GruArgs", [
     ("y", _P), ("hstate", _P), ("saved", _P), ("hprev_bf", _P),
     ("dy", _P), ("ld_dy", _I64), ("mask", _P),
     ("dgi", _P), ("dgh", _P), ("dhstate", _P),
-    ("B", _I32), ("T", _I32), ("H", _I32)])
+    ("B", _I32), ("T", _I32), ("H", _I32), ("ws_floats", _I64)])
 
 _SIGS = {
     "stes_gemm": [_P, _P],
@@ -112,7 +112,7 @@ _SIGS = {
     "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
-EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats"] + list(_SIGS)
+EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats"] + list(_SIGS)
 
 
 def lib():
@@ -126,6 +126,8 @@ def lib():
         L.stes_version.restype = C.c_int
         L.stes_gsm_bwd_conv_ws_floats.argtypes = [C.c_int]
         L.stes_gsm_bwd_conv_ws_floats.restype = C.c_int
+        L.stes_gru_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.stes_gru_ws_floats.restype = C.c_int64
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig

@@ -537,6 +537,41 @@ def _pack_gru(sd, l, H):
     return wih, bih, whh, bhh
 
 
+@pytest.mark.parametrize("B,T,H", [(16, 64, 768), (9, 5, 256), (16, 3, 96), (3, 7, 768)])
+def test_gru_one_launch_recurrence_bit_identical(B, T, H):
+    """The whole recurrence in one launch (hidden state exchanged between workgroups through the workspace) against the
+    launch-per-step form: forward outputs, everything saved for the backward, and the backward's gate gradients, bit for bit."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
+    M = B * T
+    gi = dev((torch.randn(M, 6 * H, generator=g) * 0.5).to(BF))
+    whh = torch.randn(2, 3 * H, H, generator=g) / H ** 0.5
+    whh_d, whhT_d = dev(whh.to(BF)), dev(whh.transpose(1, 2).contiguous().to(BF))
+    bhh = dev(torch.randn(2, 3 * H, generator=g) * 0.1)
+    dy = dev(torch.randn(B, T, 2 * H, generator=g))
+    L = lib.lib()
+    outs = []
+    for one_launch in (False, True):
+        nf = L.stes_gru_ws_floats(B, H, 0) if one_launch else 4 * B * H
+        nb = L.stes_gru_ws_floats(B, H, 1) if one_launch else 4 * B * H
+        y = torch.zeros(B, T, 2 * H, dtype=BF, device="cuda")
+        hstate = torch.full((nf,), 7.0, device="cuda")        # (the workspace need not be cleared by the caller)
+        saved = torch.zeros(2, T, B, 5, H, device="cuda"); hprev = torch.zeros(2, T, B, H, dtype=BF, device="cuda")
+        a = lib.gru_args(gi=gi, whh=whh_d, whhT=whhT_d, bhh=bhh, y=y, hstate=hstate, saved=saved, hprev_bf=hprev, B=B, T=T, H=H,
+                         ws_floats=nf if one_launch else 0)
+        lib.check(L.stes_gru_forward(C.byref(a), lib.stream()), "gru fwd")
+        dgi = torch.zeros(M, 6 * H, dtype=BF, device="cuda"); dgh = torch.zeros(2, T, B, 3 * H, dtype=BF, device="cuda")
+        dhs = torch.full((nb,), 7.0, device="cuda")
+        a = lib.gru_args(gi=gi, whh=whh_d, whhT=whhT_d, bhh=bhh, y=y, hstate=hstate, saved=saved, hprev_bf=hprev, dy=dy, ld_dy=2 * H,
+                         dgi=dgi, dgh=dgh, dhstate=dhs, B=B, T=T, H=H, ws_floats=nb if one_launch else 0)
+        lib.check(L.stes_gru_backward(C.byref(a), lib.stream()), "gru bwd")
+        torch.cuda.synchronize()
+        outs.append((y, saved, hprev, dgi, dgh))
+    assert float(outs[0][0].float().abs().max()) > 0.05        # a live recurrence
+    for name, a_, b_ in zip(("y", "saved", "hprev", "dgi", "dgh"), outs[0], outs[1]):
+        assert torch.equal(a_, b_), name
+
+
 def test_gru_layer_vs_reference_golden(golden):
     """One bidirectional GRU layer forward + BPTT against torch.nn.GRU as run by the reference's GRUPrediction."""
     from spot_amd import lib
