@@ -1,0 +1,114 @@
+"""The data-parallel trainer with TWO ranks on the real engine.  Both ranks are fresh child processes that share the one
+GPU of the test box; the process group is gloo, so gradient buckets and broadcasts are staged through host memory by a
+small adapter with torch.distributed's calling convention (RCCL needs one GPU per rank; the trainer only sees the
+adapter).  Checked: the bucketed all-reduce issued from inside backward delivers the SUM of the two ranks' gradients, each
+taken with the GLOBAL loss denominators (reference train_e2e_spatial.py:569-572,589-591), and both ranks hold identical
+weights after AdamW."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _HostStaged:
+    """torch.distributed's all_reduce / broadcast on device tensors through host copies (gloo)."""
+
+    def __init__(self, dist):
+        self._d, self.ReduceOp = dist, dist.ReduceOp
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_reduce(self, t, op=None, async_op=False):
+        h = t.detach().cpu()
+        self._d.all_reduce(h, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(h)
+        return self._Done()
+
+    def broadcast(self, t, src=0):
+        h = t.detach().cpu()
+        self._d.broadcast(h, src=src)
+        t.copy_(h)
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import stes_oracle as O
+    from spot_amd import dp
+    from spot_amd.e2e import E2EModel
+
+    def build(seed):
+        om = O.Impl(7, "rny008_gsm", "gru", clip_len=4, predict_location=True)
+        O.randomize_(om, seed=seed)
+        m = E2EModel(7, "rny008_gsm", "gru", clip_len=4, modality="rgb", device="cuda", predict_location=True, verbose=False)
+        m._model.load_state_dict(om.state_dict(), strict=True)
+        m._model._pred_fine._dropout.p = 0.0
+        m._model.engine.drop_p = 0.0
+        return m
+
+    g = torch.Generator().manual_seed(21)                       # the global batch: four clips, two per rank
+    x = torch.randn(4, 4, 3, 64, 64, generator=g)
+    label = torch.randint(0, 7, (4, 4), generator=g)
+    label[0, 0] = 0; label[3, 1] = 2
+    xy = torch.rand(4, 4, 2, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    xr, lr_, xyr = x[sl].cuda(), label[sl].cuda(), xy[sl].cuda()
+    den = dp.loss_denominators(label.cuda(), 5.0)               # over ALL ranks' labels
+    # this rank's own gradient with the global denominators, no optimizer step
+    m1 = build(5)
+    m1.train_step(xr, lr_, xyr, lr=1e-3, ext_denoms=den, optimizer_step=False)
+    torch.cuda.synchronize()
+    own = m1._model.engine.flat_grad.detach().cpu().clone()
+    # the data-parallel step (rank 1 starts from other weights: the trainer must broadcast rank 0's)
+    m2 = build(5 if rank == 0 else 6)
+    trainer = dp.DataParallelTrainer(m2, _HostStaged(dist), lr=1e-3)
+    out = trainer.step(xr, lr_, xyr).cpu()
+    torch.cuda.synchronize()
+    eng = m2._model.engine
+    torch.save({"own": own, "reduced": eng.flat_grad.detach().cpu(), "weights": eng.flat.detach().cpu(), "out": out, "den": den.cpu(),
+                "buckets": dict(eng.buckets)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_engine_step_sums_gradients_and_keeps_replicas_identical(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=110)
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(2))
+    # both ranks hold the same reduced gradient and the same weights after AdamW, bit for bit
+    assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["weights"], r1["weights"])
+    # every rank divided by the same denominators, and they are the sums of the ranks' own class-weight sums / event counts
+    assert torch.equal(r0["den"], r1["den"]) and (r0["out"][3:5] + r1["out"][3:5]).tolist() == r0["den"].tolist()
+    want = (r0["own"] + r1["own"]).double()
+    got = r0["reduced"].double()
+    for name, (lo, hi) in r0["buckets"].items():
+        a, b = got[lo:hi], want[lo:hi]
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        print("bucket %-6s [%9d, %9d): cosine %.5f  rel L2 %.4f" % (name, lo, hi, cos, rel))
+        # (two runs of the same step differ by the order of their fp32 atomic adds, which moves BatchNorm statistics in the
+        # last bits and with them a few bf16 roundings; a wrong bucket, a missing rank or a per-rank denominator would be
+        # off by tens of percent)
+        assert cos > 0.98 and rel < 0.2, (name, cos, rel)
+    # the summed loss partials are the global-batch loss: each rank normalised by the global denominators
+    tot = (r0["out"][:3] + r1["out"][:3]).numpy()
+    assert np.isfinite(tot).all() and abs(tot[0] - (tot[1] + tot[2])) < 1e-4 * max(1.0, abs(tot[0]))

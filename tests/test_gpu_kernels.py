@@ -537,6 +537,50 @@ def _pack_gru(sd, l, H):
     return wih, bih, whh, bhh
 
 
+def test_loc_mlp_vs_reference_golden(golden):
+    """The location head (reference train_e2e_spatial.py:400-410, model/common.py:78-92: Linear-ReLU-Linear, then Linear) as
+    the engine runs it -- three stes_gemm forward, stes_gemm / stes_wgrad backward -- against the reference module's own
+    output, input gradient and parameter gradients."""
+    from spot_amd import lib
+    z = golden("loc_mlp")
+    x = torch.from_numpy(z["x"]); gy = torch.from_numpy(z["gy"])
+    M, I = x.shape[0] * x.shape[1], x.shape[2]
+    W = [torch.from_numpy(z["p." + k + ".weight"]) for k in ("0.layers.0", "0.layers.1", "1")]
+    Bs = [dev(torch.from_numpy(z["p." + k + ".bias"])) for k in ("0.layers.0", "0.layers.1", "1")]
+    Wb = [dev(w.to(BF)) for w in W]
+    WT = []
+    for w in W:                                            # [K][N8]: transposed copies with the output width padded to 8
+        t = torch.zeros(w.shape[1], (w.shape[0] + 7) // 8 * 8)
+        t[:, :w.shape[0]] = w.t()
+        WT.append(dev(t.to(BF)))
+    xb = dev(x.reshape(M, I).to(BF))
+    h1 = torch.empty(M, 96, dtype=BF, device="cuda"); h2 = torch.empty(M, 32, dtype=BF, device="cuda"); y = torch.empty(M, 2, device="cuda")
+    lib.gemm(xb, Wb[0], h1, M, 96, I, bias=Bs[0], act=1)
+    lib.gemm(h1, Wb[1], h2, M, 32, 96, bias=Bs[1])
+    lib.gemm(h2, Wb[2], y, M, 2, 32, bias=Bs[2])
+    torch.cuda.synchronize()
+    close(y.cpu().reshape(z["y"].shape), torch.from_numpy(z["y"]), 2e-2, 2e-2)
+    # backward, as Engine.backward runs it
+    dy8 = torch.zeros(M, 8); dy8[:, :2] = gy.reshape(M, 2)
+    dy8 = dev(dy8.to(BF))
+    g = [torch.zeros_like(w).cuda() for w in W]; gb = [torch.zeros_like(b) for b in Bs]
+    lib.wgrad(dy8, h2, g[2], M, 2, 32, ldp=8, dbias=gb[2])
+    dh2 = torch.empty(M, 32, dtype=BF, device="cuda")
+    lib.gemm(dy8, WT[2], dh2, M, 32, 8, ldw=WT[2].shape[1])
+    lib.wgrad(dh2, h1, g[1], M, 32, 96, dbias=gb[1])
+    dh1 = torch.empty(M, 96, dtype=BF, device="cuda")
+    lib.gemm(dh2, WT[1], dh1, M, 96, 32, ldw=WT[1].shape[1], relu_mask=h1, ldmask=96)
+    lib.wgrad(dh1, xb, g[0], M, 96, I, dbias=gb[0])
+    dx = torch.empty(M, I, device="cuda")
+    lib.gemm(dh1, WT[0], dx, M, I, 96, ldw=WT[0].shape[1])
+    torch.cuda.synchronize()
+    ref = lambda k: torch.from_numpy(z[k])
+    assert float((dx.cpu().reshape(z["gx"].shape) - ref("gx")).norm() / ref("gx").norm()) < 2e-2
+    for i, k in enumerate(("0.layers.0", "0.layers.1", "1")):
+        assert float((g[i].cpu() - ref("g." + k + ".weight")).norm() / ref("g." + k + ".weight").norm()) < 2e-2, k
+        assert float((gb[i].cpu() - ref("g." + k + ".bias")).norm() / ref("g." + k + ".bias").norm()) < 2e-2, k
+
+
 @pytest.mark.parametrize("B,T,H", [(16, 64, 768), (9, 5, 256), (16, 3, 96), (3, 7, 768)])
 def test_gru_one_launch_recurrence_bit_identical(B, T, H):
     """The whole recurrence in one launch (hidden state exchanged between workgroups through the workspace) against the

@@ -14,6 +14,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+# per-tensor gradient criterion of the 128x128 composite: for every tensor with signal whose fp32 gradient the CPU oracle
+# itself reproduces within TIGHT_YARD under bf16 storage rounding (ReLU-mask flips decide the rest), cosine with and
+# relative L2 distance from the fp32 gradient
+TIGHT_YARD, TIGHT_COS, TIGHT_REL = 0.10, 0.95, 0.15
+
+
 def rel(a, b):
     a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-12))
@@ -58,14 +64,17 @@ def test_eval_forward_vs_reference_golden(golden):
     np.testing.assert_allclose(loc, oloc, atol=2e-2)
 
 
-@pytest.mark.parametrize("arch,tarch,tag", [("rny008_gsm", "gru", "full_rny008_gsm_gru"), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru")])
-def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag):
+@pytest.mark.parametrize("arch,tarch,tag,clip_len", [("rny008_gsm", "gru", "full_rny008_gsm_gru", 4), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru", 4),
+                                                     ("rny008_gsm", "gru", "full_rny008_gsm_gru_128", 8)])
+def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag, clip_len):
     """Training-mode outputs, loss and every parameter gradient against the reference's own fp32 run (golden) -- for the
     plain temporal shift this includes the autograd consequences of the reference's in-place shift (model/shift.py:55-78):
-    unshifted shortcut gradient, ReLU mask taken from the shifted tensor."""
+    unshifted shortcut gradient, ReLU mask taken from the shifted tensor.  The 128x128 case (16 frames, 4x4 final map) is
+    the one where bf16 storage noise flips few ReLU masks per channel: it carries the tight per-tensor criterion."""
     from oracle import stes_oracle as O
     z = golden(tag)
-    om, m = build(arch, tarch)
+    tight = clip_len == 8
+    om, m = build(arch, tarch, clip_len=clip_len)
     x, label, xy = torch.from_numpy(z["x"]), torch.from_numpy(z["label"]), torch.from_numpy(z["xy"])
     impl = m._model
     impl.train()
@@ -112,7 +121,7 @@ def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag
     # close to the reference's fp32 gradient as the bf16-rounded oracle is (ratio of the two deviations: median < 1.3,
     # 95th percentile < 2, max < 3.5 over all tensors), with cosine > 0.75 for 95 % of the tensors and > 0.55 for all (the
     # tensors of the first block sit behind the whole chain of masks: about one run in ten one of them lands at 0.7).
-    om32 = O.Impl(7, arch, tarch, clip_len=4, predict_location=True)
+    om32 = O.Impl(7, arch, tarch, clip_len=clip_len, predict_location=True)
     O.randomize_(om32, seed=3)
     om32.train()
     if tarch == "gru":
@@ -129,8 +138,9 @@ def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag
         if p.grad is None:
             continue
         ref = torch.from_numpy(z["g." + n]) if "g." + n in z.files else g32[n]     # reference's own fp32 gradient when stored
-        # the stored reference norms pin the oracle's fp32 gradient for every tensor
-        assert abs(float(g32[n].double().norm()) - norms[n]) <= 2e-3 * norms[n] + 1e-7, n
+        # the stored reference norms pin the oracle's fp32 gradient for every tensor (fp32 summation order differs between
+        # hosts and thread counts: 0.3 % was seen on a two-element bias gradient summed over 200,000 positions)
+        assert abs(float(g32[n].double().norm()) - norms[n]) <= (1e-2 if tight else 2e-3) * norms[n] + 1e-7, n
         ours, yard = rel(p.grad.cpu(), ref), rel(g16[n], ref)
         a, b = p.grad.cpu().double().flatten(), ref.double().flatten()
         cosine = float(a @ b / (a.norm() * b.norm() + 1e-30))
@@ -138,8 +148,21 @@ def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag
         if norms[n] > 1e-2 * med and p.numel() >= 64:
             ratios.append(ours / max(yard, 2e-2))
             cosines.append(cosine)
-            assert cosine > 0.55, (n, cosine)
+            assert tight or cosine > 0.55, (n, cosine, ours, yard)
     ratios = np.array(ratios)
+    if tight:
+        sig = [r for r in report if norms[r[3]] > 1e-2 * med and dict(impl.named_parameters())[r[3]].numel() >= 64]
+        quiet = [r for r in sig if r[1] < TIGHT_YARD]      # tensors whose fp32 gradient survives bf16 storage in the CPU oracle itself
+        print("128x128 composite: %d tensors with signal, %d of them with a bf16-oracle deviation below %.2f" % (len(sig), len(quiet), TIGHT_YARD))
+        print("  those: cosine min %.4f, rel L2 max %.4f;  all: cosine min %.4f p5 %.4f, rel L2 median %.4f" % (
+            min(r[2] for r in quiet), max(r[0] for r in quiet), min(r[2] for r in sig), np.percentile([r[2] for r in sig], 5),
+            np.median([r[0] for r in sig])))
+        for r in quiet:
+            assert r[2] > TIGHT_COS and r[0] < TIGHT_REL, r
+        # everywhere else the CPU oracle under bf16 storage rounding is itself 20-50 % away from its fp32 run at this size too
+        # (median 0.36: the random-init net stays sensitive to ReLU-mask flips however large the batch), so the criterion
+        # there is the distribution of ours / yardstick below plus a cosine floor (measured minimum 0.87)
+        assert len(quiet) >= 10 and min(r[2] for r in sig) > 0.8, sorted(sig, key=lambda r: r[2])[:4]
     assert np.percentile(cosines, 5) > 0.75, sorted(cosines)[:8]
     print("ours/yardstick: median %.2f  p95 %.2f  max %.2f over %d tensors" % (np.median(ratios), np.percentile(ratios, 95), ratios.max(), len(ratios)))
     # one noise realisation per run (the fp32 atomics reorder), so the criterion is on the distribution over the 250+ tensors
