@@ -81,8 +81,14 @@ typedef struct {
      * tensor under the BatchNorm whose output gradient is P, the operand is bf16(bn_alpha*P + bn_beta*p_raw + bn_delta) --
      * the tensor stes_bn_bwd_apply would have written.  For layers with no input gradient (the stem).                   */
     const uint16_t* p_raw; const float* bn_alpha; const float* bn_beta; const float* bn_delta;
+    /* Optional workspace of ws_floats floats (contents irrelevant on entry, garbage on return).  The 320 x 320 products of
+     * stage 3 (M a multiple of 32, at least 8192 rows, no dbias) run on a kernel that owns whole 320-column strips per row
+     * chunk; with stes_wgrad_ws_floats() floats every row chunk writes its partial result to its own slab and a second
+     * launch adds the slabs to dW, instead of 128 chunks adding 400 KiB each by fp32 atomics (40 % of that kernel's time). */
+    float* ws; int64_t ws_floats;
 } stes_wgrad_args;
 int stes_wgrad(const stes_wgrad_args* a, void* stream);
+int64_t stes_wgrad_ws_floats(void);
 
 /* ---------------------------------------------------- BatchNorm / block glue ----
  * Training-mode BatchNorm2d/3d is split around the convolutions: the producing kernel

@@ -571,6 +571,193 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     }
 }
 
+// ------------------------------------------------------------------ weight gradient, 320 x 320 (stage 3): strip kernel
+// dW[320][320] = P^T pro(Q) is bound by reading P and Q once; the 128 x 128 tiles above read each operand three times (from
+// L2, when the tiles of a row chunk stay in step) behind a single 64-row prefetch.  Here a workgroup of eight waves owns
+// ALL 320 columns of P against a 160-column half of Q for its row chunk (accumulators: 5 x 5 fragments per wave), so P
+// is read twice and Q once, and the operands travel global -> LDS directly (no staging registers) through a ring of four
+// 32-row steps: three steps' loads (90 KiB per CU) are always in flight, one workgroup barrier per step.
+// LDS image: 1 KiB pieces of 16 rows x 32 channels, one per load instruction (lane = row, 16-byte chunk; rows 8-15 hold
+// their two 32-byte halves swapped, a swizzle applied to the per-lane SOURCE address, which makes the transposed
+// fragment reads conflict-free).  The Q prologue (BatchNorm + ReLU + squeeze-excite gate) runs in place in LDS, each
+// wave on the pieces it loaded itself, before the step's barrier.  M must be a multiple of 32.
+constexpr int WS_N1 = 320, WS_NQ = 160, WS_STAGES = 4, WS_PIECES = 30, WS_GMAX = 12;
+constexpr int WS_STAGE_BYTES = WS_PIECES * 1024;
+
+template <bool PRO, bool SLAB>
+__global__ __launch_bounds__(512) void wgrad_strip_kernel(const stes_wgrad_args p, int m_chunk, RowDivs dv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
+    float* sc_s = reinterpret_cast<float*>(ws_smem + WS_STAGES * WS_STAGE_BYTES);      // [160]
+    float* sh_s = sc_s + WS_NQ;                                                         // [160]
+    float* gate_s = sh_s + WS_NQ;                                                       // [WS_GMAX][160]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qhalf = blockIdx.x & 1, mblk = blockIdx.x >> 1;
+    const long m_begin = (long)mblk * m_chunk;
+    const long m_end = (m_begin + m_chunk < p.M) ? m_begin + m_chunk : p.M;
+    if (m_begin >= m_end) return;
+    const int nsteps = (int)((m_end - m_begin) >> 5);
+    const bf16* __restrict__ P = (const bf16*)p.P;
+    const bf16* __restrict__ Q = (const bf16*)p.Q;
+    const bf16* __restrict__ Q0 = (const bf16*)p.Q0;
+    const int img0 = PRO && p.q_gate ? (int)fdiv((uint32_t)m_begin, dv.gate) : 0;
+    if (PRO) {
+        for (int i = tid; i < WS_NQ; i += 512) { sc_s[i] = p.q_scale ? p.q_scale[qhalf * WS_NQ + i] : 1.f; sh_s[i] = p.q_scale ? p.q_shift[qhalf * WS_NQ + i] : 0.f; }
+        const int nimg = p.q_gate ? (int)fdiv((uint32_t)(m_end - 1), dv.gate) - img0 + 1 : 0;
+        for (int i = tid; i < nimg * WS_NQ; i += 512) {
+            const int g = i / WS_NQ, c = i - g * WS_NQ;
+            gate_s[i] = p.q_gate[(long)(img0 + g) * p.N2 + qhalf * WS_NQ + c];
+        }
+    }
+    // ---- this wave's pieces of a step: q = wave, wave + 8, ... < 30; q < 20: P piece (row half q / 10, 32-column piece q % 10)
+    const int n_mine = wave < 6 ? 4 : 3;
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ (2 * ((lrow >> 3) & 1));            // row in the piece, SOURCE chunk of this lane
+    auto issue = [&](int step) {
+        const long mrow = m_begin + (long)step * 32;
+        unsigned char* stage = ws_smem + (step % WS_STAGES) * WS_STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wave + 8 * u;
+            if (q >= WS_PIECES) break;
+            const bf16* src;
+            if (q < 20) {
+                const int rp = q / 10, cp = q - rp * 10;
+                src = P + (mrow + rp * 16 + lrow) * p.ldp + cp * 32 + lchunk * 8;
+            } else {
+                const int q2 = q - 20, rp = q2 / 5, cp = q2 - rp * 5;
+                long m = mrow + rp * 16 + lrow;
+                if (p.map_stride > 1) {
+                    uint32_t n, rem, ho, wo;
+                    fdivmod((uint32_t)m, dv.hw, n, rem);
+                    fdivmod(rem, dv.wo, ho, wo);
+                    m = ((long)n * p.Hi + (long)ho * p.map_stride) * p.Wi + (long)wo * p.map_stride;
+                }
+                const int c = qhalf * WS_NQ + cp * 32 + lchunk * 8;
+                src = c < p.k0 ? Q0 + m * p.ldq0 + c : Q + m * p.ldq + c;
+            }
+            // (as inline asm: the compiler drains every outstanding load before the first LDS read that follows an LDS-DMA it
+            // knows about, which would serialise the ring; the waits below are counted by hand)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(stage + q * 1024));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+        }
+    };
+    // ---- Q prologue in place, on the pieces this wave loaded (their bytes have landed: the wave waited for its own loads)
+    auto transform = [&](int step) {
+        unsigned char* stage = ws_smem + (step % WS_STAGES) * WS_STAGE_BYTES;
+        const long mrow = m_begin + (long)step * 32;
+#pragma unroll
+        for (int u = 2; u < 4; ++u) {
+            const int q = wave + 8 * u;
+            if (q < 20 || q >= WS_PIECES) continue;
+            const int q2 = q - 20, rp = q2 / 5, cp = q2 - rp * 5;
+            const int c = cp * 32 + lchunk * 8;                                           // channel within the 160-column half
+            bf16x8* cell = reinterpret_cast<bf16x8*>(stage + q * 1024 + lane * 16);
+            float f[8], sc[8], sh[8];
+            unpack8(*cell, f);
+            load8f(sc_s + c, sc); load8f(sh_s + c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] = f[e] * sc[e] + sh[e];
+                if (p.q_relu) f[e] = fmaxf(f[e], 0.f);
+            }
+            if (p.q_gate) {
+                float g[8];
+                load8f(gate_s + ((int)fdiv((uint32_t)(mrow + rp * 16 + lrow), dv.gate) - img0) * WS_NQ + c, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= g[e];
+            }
+            *cell = pack8(f);
+        }
+    };
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int w1 = wave & 3, w2 = wave >> 2;               // 80 columns of P x 80 columns of Q per wave
+    // transposed fragment reads: lane group fq supplies rows 8 (fq & 1) + (fr >> 2) (+ 4) of row half fq >> 1
+    const int roff = ((fq >> 1) * 10) * 1024 + (8 * (fq & 1) + (fr >> 2)) * 64 + (fr & 3) * 8;   // P pieces; Q: row half stride 5 pieces
+    const int qoff = 20 * 1024 + ((fq >> 1) * 5) * 1024 + (8 * (fq & 1) + (fr >> 2)) * 64 + (fr & 3) * 8;
+    const int sw = 2 * (fq & 1);                           // rows 8-15 of a piece hold their 32-byte halves swapped
+
+    __syncthreads();                                       // prologue tables
+#pragma unroll 1
+    for (int s0 = 0; s0 < WS_STAGES - 1 && s0 < nsteps; ++s0) issue(s0);
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        // this wave's loads of `step` have landed when at most the later steps' loads are outstanding
+        const int later = nsteps - 1 - step < WS_STAGES - 2 ? nsteps - 1 - step : WS_STAGES - 2;
+        if (n_mine == 4) {
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (PRO) { transform(step); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();                      // every wave's pieces of `step` are in LDS; everyone is done with step - 1
+        if (step + WS_STAGES - 1 < nsteps) issue(step + WS_STAGES - 1);
+        const unsigned char* stage = ws_smem + (step % WS_STAGES) * WS_STAGE_BYTES;
+        bf16x8 fa[5], fb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int col = w1 * 80 + i * 16;
+            const unsigned char* a = stage + roff + (col >> 5) * 1024 + ((2 * ((col >> 4) & 1)) ^ sw) * 16;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a + 256));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int col = w2 * 80 + j * 16;
+            const unsigned char* b = stage + qoff + (col >> 5) * 1024 + ((2 * ((col >> 4) & 1)) ^ sw) * 16;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(b));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(b + 256));
+            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    // D[row = n1 (4 fq + r)][col = n2 (fr)]
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int n2 = qhalf * WS_NQ + w2 * 80 + j * 16 + fr;
+            const int n2d = n2 < p.perm_fold ? gsm_dest(n2, p.perm_fold) : n2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = w1 * 80 + i * 16 + fq * 4 + r;
+                // (with a workspace: this chunk's own slab, plain stores, summed by wgrad_strip_fold_kernel -- 128 chunks of fp32
+                // atomics into the same 400 KiB cost 42 us of the kernel's 102)
+                if (SLAB) p.ws[((long)mblk * WS_N1 + n1) * (2 * WS_NQ) + n2d] = acc[i][j][r];
+                else atomicAdd(p.dW + (long)n1 * p.lddw + n2d, acc[i][j][r]);
+            }
+        }
+}
+
+// dW += sum of the row chunks' slabs [mb][320][320]; grid (320*320/256, slab groups): a thread adds up its group's slabs for one
+// element (coalesced across the workgroup) and then adds once to dW
+__global__ __launch_bounds__(256) void wgrad_strip_fold_kernel(const float* __restrict__ ws, int mb, float* __restrict__ dW, long lddw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = (mb + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = s0 + per < mb ? s0 + per : mb;
+    constexpr int NEL = WS_N1 * 2 * WS_NQ;
+    float a = 0.f;
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4) {
+        const float v0 = ws[(long)sl * NEL + i], v1 = ws[(long)(sl + 1) * NEL + i], v2 = ws[(long)(sl + 2) * NEL + i], v3 = ws[(long)(sl + 3) * NEL + i];
+        a += (v0 + v1) + (v2 + v3);
+    }
+    for (; sl < s1; ++sl) a += ws[(long)sl * NEL + i];
+    if (s1 > s0) atomicAdd(dW + (long)(i / (2 * WS_NQ)) * lddw + i % (2 * WS_NQ), a);
+}
+
 template <int T, int WAVES>
 static size_t wgrad_lds_bytes() {
     static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -635,6 +822,8 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     return STES_OK;
 }
 
+extern "C" int64_t stes_wgrad_ws_floats(void) { return 128L * WS_N1 * 2 * WS_NQ; }
+
 extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     STES_CHECK(a && a->P && a->Q && a->dW, STES_ERR_ARG, "stes_wgrad: null pointer");
     STES_CHECK(a->M > 0 && a->N1 > 0 && a->N2 > 0, STES_ERR_ARG, "stes_wgrad: empty shape");
@@ -645,6 +834,44 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     const bool big = a->N1 > 64 && a->N2 > 64;
     STES_CHECK(!a->p_raw || (a->bn_alpha && a->bn_beta && a->bn_delta), STES_ERR_ARG, "stes_wgrad: the P prologue needs alpha/beta/delta");
     STES_CHECK(!a->p_raw || !big, STES_ERR_UNSUPPORTED, "stes_wgrad: the P prologue exists for the 64-wide tile only (N1 <= 64 or N2 <= 64)");
+    STES_CHECK(a->M <= STES_MAX_ROWS, STES_ERR_UNSUPPORTED, "stes_wgrad: more than 2^31 rows");
+    // stage 3's 320 x 320 products: the strip kernel (P read twice, Q once, LDS-DMA ring)
+    if (a->N1 == WS_N1 && a->N2 == 2 * WS_NQ && a->M % 32 == 0 && a->M >= 32 * 256 && !a->dbias && !a->p_raw && a->ldp % 8 == 0 &&
+        (a->k0 == 0 || a->k0 % 8 == 0)) {
+        const long chunk = (a->M / 32 + 127) / 128 * 32;                                // 128 row chunks x 2 halves = 256 workgroups
+        const int mb = stes_div_up(a->M, chunk);
+        const bool pro = a->q_scale || a->q_gate;
+        const long imgs = a->q_gate ? chunk / a->gate_group + 2 : 0;
+        if (imgs <= WS_GMAX) {
+            RowDivs dv;
+            dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
+            dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
+            dv.gate = make_fastdiv(a->q_gate ? a->gate_group : 1);
+            const size_t lds = (size_t)WS_STAGES * WS_STAGE_BYTES + (size_t)(2 + WS_GMAX) * WS_NQ * sizeof(float);
+            const bool slab = a->ws && a->ws_floats >= (int64_t)mb * WS_N1 * 2 * WS_NQ;
+            static const bool raised = [] {
+                bool ok = true;
+                const void* fns[4] = {reinterpret_cast<const void*>(&wgrad_strip_kernel<true, true>), reinterpret_cast<const void*>(&wgrad_strip_kernel<true, false>),
+                                      reinterpret_cast<const void*>(&wgrad_strip_kernel<false, true>), reinterpret_cast<const void*>(&wgrad_strip_kernel<false, false>)};
+                for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                return ok;
+            }();
+            if (raised) {
+                const dim3 grid(mb * 2), block(512);
+                hipStream_t st = (hipStream_t)stream;
+                if (pro && slab) hipLaunchKernelGGL((wgrad_strip_kernel<true, true>), grid, block, lds, st, *a, (int)chunk, dv);
+                else if (pro) hipLaunchKernelGGL((wgrad_strip_kernel<true, false>), grid, block, lds, st, *a, (int)chunk, dv);
+                else if (slab) hipLaunchKernelGGL((wgrad_strip_kernel<false, true>), grid, block, lds, st, *a, (int)chunk, dv);
+                else hipLaunchKernelGGL((wgrad_strip_kernel<false, false>), grid, block, lds, st, *a, (int)chunk, dv);
+                STES_LAUNCH_CHECK();
+                if (slab) {
+                    hipLaunchKernelGGL(wgrad_strip_fold_kernel, dim3(WS_N1 * 2 * WS_NQ / 256, 8), dim3(256), 0, st, a->ws, mb, a->dW, (long)a->lddw);
+                    STES_LAUNCH_CHECK();
+                }
+                return STES_OK;
+            }
+        }
+    }
     const int t = big ? 128 : 64;
     const int t1 = stes_div_up(a->N1, t), t2 = stes_div_up(a->N2, t);
     // Split the rows so that the grid has about `total` workgroups, at least 256 rows each.  The 128-tile holds two

@@ -238,7 +238,7 @@ class Block:
             lib.gemm(dc3, self.l3.wT_bf, dA3, Mo, cmid, cout, ldw=self.l3.Np)
         # --- conv3 (1x1) weight gradient
         side(lambda: lib.wgrad(dc3, self.c2, g(self.l3.w), Mo, cout, cmid, scale=bn2.scale, shift=bn2.shift, relu=True,
-                               gate=self.segate, gate_group=HWo))
+                               gate=self.segate, gate_group=HWo, ws=e.wgrad_ws(cout, cmid)))
         # --- squeeze-excite backward
         dgate = sc("se.dgate", self.N * cmid, F32)
         S4 = sc("se.S4", 4 * self.N * cmid, F32)
@@ -276,7 +276,7 @@ class Block:
         else:
             lib.bn_bwd_apply(dA2, self.c1, Mi, cmid, bn1.coef, dc1)
             lib.gemm(dc1, self.l1.wT_bf, dY1, Mi, cin, cmid, **kw1)
-        side(lambda: lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold))
+        side(lambda: lib.wgrad(dc1, a_src, g(self.l1.w), Mi, cmid, cin, Q0=q0, ldq0=k0, k0=k0, perm_fold=self.fold, ws=e.wgrad_ws(cmid, cin)))
         dXf = None
         if self.kind == "gsm":
             gs, bng, geom, Xc, fold = self.gsm, self.bng, self.geom, self.Xc, self.fold
@@ -412,6 +412,16 @@ class Engine:
                 t.record_stream(self.side)       # the side stream may still be reading the tensor being replaced
             t = torch.empty(numel, dtype=dtype, device=self.dev)
             self._scratch[name] = t
+        return t
+
+    def wgrad_ws(self, n1, n2):
+        """Slab workspace of the 320 x 320 weight-gradient kernel (None for other shapes).  One buffer: the weight gradients
+        that use it run one after the other on one stream."""
+        if n1 != 320 or n2 != 320:
+            return None
+        t = self._scratch.get("wgrad.ws")
+        if t is None:
+            t = self._scratch["wgrad.ws"] = torch.empty(lib.lib().stes_wgrad_ws_floats(), device=self.dev)
         return t
 
     def gsm_ws(self, fold):

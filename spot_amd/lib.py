@@ -46,7 +46,7 @@ WgradArgs = _struct("WgradArgs", [
     ("map_stride", _I32), ("Ho", _I32), ("Wo", _I32), ("Hi", _I32), ("Wi", _I32),
     ("dW", _P), ("lddw", _I64), ("dbias", _P), ("perm_fold", _I32),
     ("M", _I64), ("N1", _I32), ("N2", _I32),
-    ("p_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P)])
+    ("p_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("ws", _P), ("ws_floats", _I64)])
 
 BnBwdArgs = _struct("BnBwdArgs", [
     ("D", _P), ("mul", _P), ("add", _P), ("group", _I32),
@@ -112,7 +112,7 @@ _SIGS = {
     "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
-EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats"] + list(_SIGS)
+EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats", "stes_wgrad_ws_floats"] + list(_SIGS)
 
 
 def lib():
@@ -128,6 +128,8 @@ def lib():
         L.stes_gsm_bwd_conv_ws_floats.restype = C.c_int
         L.stes_gru_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
         L.stes_gru_ws_floats.restype = C.c_int64
+        L.stes_wgrad_ws_floats.argtypes = []
+        L.stes_wgrad_ws_floats.restype = C.c_int64
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig
@@ -272,7 +274,7 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
 
 
 def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0, k0=0,
-          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None, perm_fold=0, bn_bwd=None):
+          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None, dbias=None, perm_fold=0, bn_bwd=None, ws=None):
     """dW += P^T pro(Q); see stes_wgrad in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta)): BatchNorm backward on P."""
     a = WgradArgs()
     a.P, a.ldp = ptr(P), ldp if ldp is not None else N1
@@ -285,10 +287,14 @@ def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0
     a.dW, a.lddw, a.dbias = ptr(dW), lddw if lddw is not None else N2, ptr(dbias)
     a.perm_fold = perm_fold
     a.M, a.N1, a.N2 = M, N1, N2
+    if ws is not None:
+        a.ws, a.ws_floats = ptr(ws), ws.numel()
     if bn_bwd is not None:
         a.p_raw, (a.bn_alpha, a.bn_beta, a.bn_delta) = ptr(bn_bwd[0]), [ptr(t) for t in bn_bwd[1]]
     if TIMING is not None:
-        _timed("wgrad_kernel<128, 8>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64, 4>", 2 * M * (N1 + N2 + (N1 if bn_bwd else 0)), 2 * M * N1 * N2,
+        strip = N1 == 320 and N2 == 320 and M % 32 == 0 and M >= 8192 and dbias is None and bn_bwd is None    # the rule in stes_gemm.hip
+        kernel = "wgrad_strip_kernel" if strip else ("wgrad_kernel<128, 8>" if N1 > 64 and N2 > 64 else "wgrad_kernel<64, 4>")
+        _timed(kernel, 2 * M * (N1 + N2 + (N1 if bn_bwd else 0)), 2 * M * N1 * N2,
                lambda: check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad"))
         return
     check(lib().stes_wgrad(C.byref(a), stream()), "stes_wgrad")

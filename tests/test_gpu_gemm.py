@@ -169,6 +169,57 @@ def test_wgrad(M, N1, N2):
     torch.testing.assert_close(db.cpu(), P[:, :N1].float().sum(0), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("slab", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "prologue", "gated", "compact", "rowmap"])
+def test_wgrad_strip_320(mode, slab):
+    """The 320 x 320 weight gradient of stage 3 (strip kernel: LDS-DMA ring, the Q prologue in place in LDS) with every operand
+    option its callers use: BatchNorm + ReLU (+ squeeze-excite gate) on Q, the gated shift's compact source for the first
+    columns with the channel interleave on the output, the strided row map of the shortcut convolution."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(len(mode))
+    HW = 14 * 14
+    N = 48
+    M = N * HW                                                    # rows of P: 9,408 = 294 steps of 32
+    P = _bf(M, 320, g=g)
+    kw = {}
+    if mode == "rowmap":                                          # Q rows live on a 28x28 map, P rows on its stride-2 subsample
+        Hi = Wi = 28; Ho = Wo = 14
+        Qfull = _bf(N * Hi * Wi, 320, g=g)
+        q = Qfull.float().view(N, Hi, Wi, 320)[:, ::2, ::2].reshape(M, 320)
+        Qd = dev(Qfull)
+        kw["rowmap"] = (2, Ho, Wo, Hi, Wi)
+    else:
+        Q = _bf(M, 320, g=g)
+        q = Q.float()
+        Qd = dev(Q)
+    if mode in ("prologue", "gated"):
+        scale, shift = torch.rand(320, generator=g) + 0.5, torch.randn(320, generator=g) * 0.3
+        q = torch.relu(q * scale + shift)
+        kw.update(scale=dev(scale), shift=dev(shift), relu=True)
+        if mode == "gated":
+            gate = torch.rand(N, 320, generator=g)
+            q = q * gate.repeat_interleave(HW, 0)
+            kw.update(gate=dev(gate), gate_group=HW)
+        q = q.to(torch.bfloat16).float()
+    ref = P.float().t() @ q
+    if mode == "compact":                                         # first 80 columns from a compact tensor, written through dest(c)
+        fold = 80
+        Q0 = _bf(M, fold, g=g)
+        q2 = q.clone(); q2[:, :fold] = Q0.float()
+        half, quarter = fold // 2, fold // 4
+        dest = [(c // half) * half + 2 * ((c % half) % quarter) + (c % half) // quarter for c in range(fold)]
+        full = P.float().t() @ q2
+        ref = full.clone()
+        ref[:, dest] = full[:, :fold]
+        kw.update(Q0=dev(Q0), ldq0=fold, k0=fold, perm_fold=fold)
+    if slab:                                                     # per-chunk slabs + a second launch instead of fp32 atomics
+        kw["ws"] = torch.full((lib.lib().stes_wgrad_ws_floats(),), float("nan"), device="cuda")
+    dW = torch.ones(320, 320, device="cuda")                      # the result is ADDED to dW
+    lib.wgrad(dev(P), Qd, dW, M, 320, 320, **kw)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dW.cpu() - 1.0, ref, rtol=2e-3, atol=2e-3 * M ** 0.5)
+
+
 @pytest.mark.parametrize("N,K", [(32, 64), (64, 128), (128, 128), (128, 320), (320, 320)])
 def test_gemm_bn_backward_prologue_equals_apply_then_gemm(N, K):
     """The streaming GEMM's BatchNorm-backward prologue (operand = alpha*dY + beta*raw + delta, rounded to bf16, also stored

@@ -23,13 +23,14 @@ for what, M, N1, N2, calls in SHAPES:
     P = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
     Q = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
     dW = torch.zeros(N1, N2, device="cuda")
+    kw = {"ws": torch.empty(lib.lib().stes_wgrad_ws_floats(), device="cuda")} if (N1, N2) == (320, 320) else {}
     for _ in range(3):
-        lib.wgrad(P, Q, dW, M, N1, N2)
+        lib.wgrad(P, Q, dW, M, N1, N2, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
     for _ in range(reps):
-        lib.wgrad(P, Q, dW, M, N1, N2)
+        lib.wgrad(P, Q, dW, M, N1, N2, **kw)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
