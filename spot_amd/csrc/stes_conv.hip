@@ -134,26 +134,34 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
     }
 }
 
-// ------------------------------------------------------------------ forward / stride-1 input gradient, LDS row ring
-// Workgroup = (image, 64-channel block = 4 groups, one per wave).  It walks down the image keeping the input rows it
-// needs in an LDS ring (pixel stride 160 bytes: 128 of data + 32 of padding, which spreads the fragment reads over the
-// banks), so every input element is fetched from memory once and BatchNorm + ReLU is applied once, at the store into LDS.
+// ------------------------------------------------------------------ forward / stride-1 input gradient, LDS row window
+// Workgroup = (image, 64-channel block = 4 groups, one per wave).  It walks down the image keeping the input rows of the
+// current step in an LDS window (pixel stride 160 bytes: 128 of data + 32 of padding, which spreads the fragment reads
+// over the banks), so every input element is fetched from memory once and BatchNorm + ReLU is applied once, at the store
+// into LDS.  The window always starts at slot 0: the one or two rows a step shares with the next one are carried over
+// through registers, which makes every operand address "per-lane constant of the fragment + per-lane constant of the
+// k-step" (one add per read; with a ring the row wrap cost more vector instructions than the convolution itself).
 // The next step's rows travel global -> registers while the current rows are convolved.  Results are staged in LDS and
 // leave as whole 128-byte pixel rows; a thread always stores the same 8 channels, so the output statistics take 16
 // registers.
 struct RowsGeom {
     int N, Hs, Ws, Hd, Wd, C;
-    int RS, NR;                        // output rows per step, ring rows
+    int RS, NR;                        // output rows per step, window rows (RS * stride + overlap)
     FastDiv fd_wd, fd_px8;             // Wd; 8 * Ws (16-byte chunks per input row of the channel block)
 };
 constexpr int PSB = 160;               // LDS bytes per pixel
 constexpr int CONV_MAXI = 7;           // staged 16-byte chunks per thread per step
+constexpr int CONV_OVI = 4;            // carried-over 16-byte chunks per thread
+constexpr int CONV_NF = 3;             // 16-pixel fragments in flight per wave
+constexpr int CONV_NG = 5;             // fragment groups per step: at most 15 fragments = 240 pixels
+constexpr int CONV_MAXP = 196;         // output pixels per step (host side keeps RS * Wd below this)
+static_assert(CONV_NF * CONV_NG * 16 >= CONV_MAXP, "fragment groups must cover a step");
 
 template <int STRIDE, bool FLIP>
-__global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
-                                                            bf16* __restrict__ dst, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* col_sum, float* col_sumsq,
-                                                            const bf16* __restrict__ mask_raw, RowsGeom gm) {
+__global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
+                                                               bf16* __restrict__ dst, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* col_sum, float* col_sumsq,
+                                                               const bf16* __restrict__ mask_raw, RowsGeom gm) {
     // FLIP with mask_raw: the result is the gradient at a ReLU(BatchNorm(raw)) output; it is masked with
     // [scale*raw + shift > 0] on its way out and the BatchNorm-backward sums (sum dy -> col_sum, sum dy*raw -> col_sumsq)
     // are accumulated here, which saves the separate reduction pass over both tensors.
@@ -165,8 +173,10 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
     const int g = cb * 4 + wave;
     const int Hs = gm.Hs, Ws = gm.Ws, Hd = gm.Hd, Wd = gm.Wd, C = gm.C, RS = gm.RS, NR = gm.NR;
     const int ROWB = (Ws + 2) * PSB;
+    constexpr int OV = STRIDE == 1 ? 2 : 1;           // window rows shared with the next step
     constexpr int NEW = STRIDE;                       // new input rows per output row
     unsigned char* ring = smem;
+    const unsigned ring_lds = (unsigned)(size_t)smem; // LDS byte address of the window
     unsigned char* stage = smem + NR * ROWB;          // [RS*Wd][128 B]
     float* red = reinterpret_cast<float*>(stage + RS * Wd * 128);   // [2][64]
 
@@ -183,130 +193,190 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
 
-    // zero the left / right halo columns of every ring row once; they are never written again
+    // Operand addresses.  Output pixel (orow, ocol) of the step under tap (kh, kw) reads window row orow*STRIDE + kh and
+    // pixel column ocol*STRIDE + kw (column 0 is the left halo); the flipped (input gradient) form reads row orow + 2 - kh
+    // and column ocol + 2 - kw.  fbase: fragment f, this lane's pixel; tapc: k-step s, this lane's tap 2s + (q >> 1).  The
+    // tenth tap does not exist: its weights are zero and it re-reads the ninth tap's operand.
+    const int P_full = RS * Wd;
+    int* fbase = reinterpret_cast<int*>(red + 128);   // [fragments][16 pixels]: a table, not registers (the kernel is short of them)
+    for (int i = tid; i < CONV_NF * CONV_NG * 16; i += 256) {
+        int pi = i;
+        if (pi >= P_full) pi = P_full - 1;
+        uint32_t orow, ocol;
+        fdivmod((uint32_t)pi, gm.fd_wd, orow, ocol);
+        fbase[i] = (int)orow * STRIDE * ROWB + (int)ocol * STRIDE * PSB;
+    }
+    int tapc[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int t0 = 2 * s, t1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
+        const int r0 = FLIP ? 2 - t0 / 3 : t0 / 3, c0 = FLIP ? 2 - t0 % 3 : t0 % 3;
+        const int r1 = FLIP ? 2 - t1 / 3 : t1 / 3, c1 = FLIP ? 2 - t1 % 3 : t1 % 3;
+        tapc[s] = (q < 2 ? r0 * ROWB + c0 * PSB : r1 * ROWB + c1 * PSB) + wave * 32 + (q & 1) * 16;
+    }
+
+    // zero the left / right halo columns of every window row once; they are never written again
     for (int i = tid; i < NR * 2 * 8; i += 256) {
         const int r = i >> 4, side = (i >> 3) & 1, ch = i & 7;
         *reinterpret_cast<bf16x8*>(ring + r * ROWB + (side ? (Ws + 1) * PSB : 0) + ch * 16) = zero8();
     }
     if (tid < 128) red[tid] = 0.f;
 
-    const bf16* img = nullptr;
+    const bf16* img = nullptr;                           // this image, this channel block (uniform)
     bf16x8 regs[CONV_MAXI];
+    // Item k of this thread in the staging phases: 16-byte chunk `chunk` of pixel (tid >> 3) + 32k of the rows being moved,
+    // kept as (row << 16 | column); the division happens once here.  The packed value passes through an empty asm at
+    // every use: the arithmetic on it is then redone there (a few full-rate instructions) instead of its results being
+    // kept in registers across the convolution, which is short of them.
+    int item[CONV_MAXI];
+#pragma unroll
+    for (int k = 0; k < CONV_MAXI; ++k) {
+        const uint32_t pxi = (uint32_t)(tid >> 3) + 32u * k;
+        const uint32_t r = fdiv(pxi * 8u, gm.fd_px8);
+        item[k] = (int)((r << 16) | (pxi - r * (uint32_t)Ws));
+    }
     // rows [first, first + count) of the input -> registers; rows outside the image are zero rows
     auto fetch = [&](int first, int count) {
-        const int items = count * Ws * 8;
 #pragma unroll
         for (int k = 0; k < CONV_MAXI; ++k) {
-            const int i = tid + k * 256;
+            int e = item[k];
+            asm volatile("" : "+v"(e));
+            const int r = e >> 16, px = e & 0xffff, ir = first + r;
             regs[k] = zero8();
-            if (i < items) {
-                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
-                const int px = (i - (int)r * Ws * 8) >> 3, ir = first + (int)r;
-                if (ir >= 0 && ir < Hs) regs[k] = *reinterpret_cast<const bf16x8*>(img + ((long)ir * Ws + px) * C);
-            }
+            if (r < count && ir >= 0 && ir < Hs)
+                regs[k] = *reinterpret_cast<const bf16x8*>(img + (__mul24(__mul24(ir, Ws) + px, C) + chunk * 8));
         }
     };
-    auto commit = [&](int first, int count) {
-        const int items = count * Ws * 8;
+    // registers -> window rows [slot, slot + count); `first` is the input row of the first one
+    auto commit = [&](int first, int count, int slot) {
 #pragma unroll
         for (int k = 0; k < CONV_MAXI; ++k) {
-            const int i = tid + k * 256;
-            if (i < items) {
-                const uint32_t r = fdiv((uint32_t)i, gm.fd_px8);
-                const int px = (i - (int)r * Ws * 8) >> 3, ir = first + (int)r;
+            int e = item[k];
+            asm volatile("" : "+v"(e));
+            const int r = e >> 16, px = e & 0xffff, ir = first + r;
+            if (r < count) {
                 bf16x8 v = regs[k];
                 if (affine && ir >= 0 && ir < Hs) {
                     float f[8];
                     unpack8(v, f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f);
+                    for (int e2 = 0; e2 < 8; ++e2) f[e2] = fmaxf(f[e2] * sc[e2] + sh[e2], 0.f);
                     v = pack8(f);
                 }
-                *reinterpret_cast<bf16x8*>(ring + ((ir + 1) % NR) * ROWB + (px + 1) * PSB + chunk * 16) = v;
+                *reinterpret_cast<bf16x8*>(ring + __mul24(slot + r, ROWB) + __mul24(px + 1, PSB) + chunk * 16) = v;
+            }
+        }
+    };
+    // the last OV window rows -> registers -> the first OV rows (the rows the next step shares with this one)
+    bf16x8 carry[CONV_OVI];
+    auto carry_move = [&](bool load) {
+#pragma unroll
+        for (int k = 0; k < CONV_OVI; ++k) {
+            int e = item[k];
+            asm volatile("" : "+v"(e));
+            const int r = e >> 16, px = e & 0xffff;
+            if (r < OV) {
+                unsigned char* at = ring + __mul24(px + 1, PSB) + chunk * 16;
+                if (load) carry[k] = *reinterpret_cast<const bf16x8*>(at + __mul24(NR - OV + r, ROWB));
+                else *reinterpret_cast<bf16x8*>(at + __mul24(r, ROWB)) = carry[k];
             }
         }
     };
 
-    // rows before the first step's new rows: stride 1 needs {-1, 0}, stride 2 needs {-1}
-    const int base0 = STRIDE == 1 ? 1 : 0;
-    // Small images: the rows in front of the first step and the first step's rows fit the staging registers together, and
-    // then the next image's first rows are requested while this image's last step is convolved (otherwise every image of a
-    // one-step geometry would wait out a memory round trip with nothing to do).
-    const int cnt0 = base0 + 1 + RS * NEW;
-    const bool merged = cnt0 * Ws * 8 <= CONV_MAXI * 256;
-    bool have = false;                                   // the registers already hold this image's first rows
-    const long img_off = (long)cb * 64 + chunk * 8;
+    // Small images: the whole first window fits the staging registers, and then the next image's first window is requested
+    // while this image's last step is convolved (otherwise every image of a one-step geometry would wait out a memory
+    // round trip with nothing to do).
+    const bool merged = NR * Ws * 8 <= CONV_MAXI * 256;
+    bool have = false;                                   // the registers already hold this image's first window
+    const long img_off = (long)cb * 64;
+    const int nsteps = (Hd + RS - 1) / RS;
     for (int n = n_first; n < gm.N; n += n_step) {       // images of this workgroup; statistics stay in registers
-    __syncthreads();                                     // the previous image's ring and staging are no longer read
+    __syncthreads();                                     // the previous image's window and staging are no longer read
     if (merged) {
-        if (!have) { img = src + (long)n * Hs * Ws * C + img_off; fetch(-1, cnt0); }
-        commit(-1, cnt0);
+        if (!have) { img = src + (long)n * Hs * Ws * C + img_off; fetch(-1, NR); }
+        commit(-1, NR, 0);
         have = false;
     } else {
         img = src + (long)n * Hs * Ws * C + img_off;
-        fetch(-1, base0 + 1);
-        commit(-1, base0 + 1);
-        fetch(base0, RS * NEW);
+        fetch(-1, OV);
+        commit(-1, OV, 0);
+        fetch(OV - 1, RS * NEW);
     }
-    const int nsteps = (Hd + RS - 1) / RS;
-    const int P_full = RS * Wd;
     for (int st = 0; st < nsteps; ++st) {
-        const int first_new = base0 + st * RS * NEW;
-        if (!(merged && st == 0)) commit(first_new, RS * NEW);
+        const int first_new = OV - 1 + st * RS * NEW;
+        if (st > 0) carry_move(false);
+        if (!(merged && st == 0)) commit(first_new, RS * NEW, OV);
         __syncthreads();
         if (st + 1 < nsteps) fetch(first_new + RS * NEW, RS * NEW);
-        else if (merged && n + n_step < gm.N) { img = src + (long)(n + n_step) * Hs * Ws * C + img_off; fetch(-1, cnt0); have = true; }
+        else if (merged && n + n_step < gm.N) { img = src + (long)(n + n_step) * Hs * Ws * C + img_off; fetch(-1, NR); have = true; }
         const int row0 = st * RS;
         const int rows_here = (row0 + RS <= Hd) ? RS : Hd - row0;
         const int P = rows_here * Wd;
         const int nfrag = (P + 15) >> 4;
-        for (int f = 0; f < nfrag; ++f) {
-            int pi = f * 16 + p;
-            const bool valid = pi < P;
-            if (!valid) pi = P - 1;
-            uint32_t orow, ocol;
-            fdivmod((uint32_t)pi, gm.fd_wd, orow, ocol);
-            const int arow = row0 + (int)orow;            // absolute output row
-            // ring slot of the input row under tap row kh: forward reads row arow*STRIDE + kh - 1, the flipped (input
-            // gradient) form reads row arow + 1 - kh
-            int rb[3];
+        const long obase = ((long)(n * Hd + row0) * Wd) * C + cb * 64 + chunk * 8;
+        // the raw values under the mask, asked for before the convolution that hides their latency
+        bf16x8 mraw[CONV_MAXI];
+        if (masked) {
+            int t = tid;
+            asm volatile("" : "+v"(t));
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ir = FLIP ? arow + 1 - kh : arow * STRIDE + kh - 1;
-                rb[kh] = ((ir + 1) % NR) * ROWB;
-            }
-            const int colb = ((int)ocol * STRIDE) * PSB + wave * 32 + (q & 1) * 16;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                // this lane's tap of k-step s: 2s + (q >> 1)
-                const int t0 = 2 * s, t1 = 2 * s + 1;
-                const int kh0 = t0 / 3, kw0 = t0 % 3, kh1 = t1 / 3, kw1 = t1 % 3;
-                bf16x8 frag = zero8();
-                if (q < 2) {
-                    const int cw = FLIP ? 2 - kw0 : kw0;
-                    frag = *reinterpret_cast<const bf16x8*>(ring + rb[kh0] + colb + cw * PSB);
-                } else if (t1 < 9) {
-                    const int cw = FLIP ? 2 - kw1 : kw1;
-                    frag = *reinterpret_cast<const bf16x8*>(ring + rb[kh1 < 3 ? kh1 : 0] + colb + cw * PSB);
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], frag, acc, 0, 0, 0);
-            }
-            if (valid) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[r];
-                *reinterpret_cast<bf16x4*>(stage + pi * 128 + wave * 32 + q * 8) = o;
+            for (int k = 0; k < CONV_MAXI; ++k) {
+                const int px = (t >> 3) + k * 32;
+                mraw[k] = zero8();
+                if (px < P) mraw[k] = *reinterpret_cast<const bf16x8*>(mask_raw + obase + (long)px * C);
             }
         }
+        // Fragments of 16 pixels, CONV_NF at a time: all their operand reads are issued before the first MFMA and the
+        // accumulation chains are independent.  The reads go through asm with counted waits: left to itself the compiler
+        // interleaves read, wait and MFMA, and the loop runs at one LDS round trip per k-step.  (A second register set that
+        // keeps the next group's reads in flight during the MFMAs measured no faster and costs 60 registers.)
+#pragma unroll 1
+        for (int gi = 0; gi < CONV_NG; ++gi) {
+            if (gi * CONV_NF < nfrag) {
+                bf16x8 frag[5][CONV_NF];
+                unsigned fb[CONV_NF];
+#pragma unroll
+                for (int u = 0; u < CONV_NF; ++u) fb[u] = ring_lds + (unsigned)fbase[(gi * CONV_NF + u) * 16 + p];
+#pragma unroll
+                for (int s = 0; s < 5; ++s)
+#pragma unroll
+                    for (int u = 0; u < CONV_NF; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(frag[s][u]) : "v"(fb[u] + (unsigned)tapc[s]));
+                f32x4 acc[CONV_NF];
+#pragma unroll
+                for (int u = 0; u < CONV_NF; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                static_assert(CONV_NF == 3, "the counted waits below release three reads each");
+#define CONV_KSTEP(S, CNT)                                                                                                    \
+                asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(frag[S][0]), "+v"(frag[S][1]), "+v"(frag[S][2]));            \
+                _Pragma("unroll") for (int u = 0; u < CONV_NF; ++u)                                                           \
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S], frag[S][u], acc[u], 0, 0, 0);                     \
+                __builtin_amdgcn_sched_barrier(0);
+                CONV_KSTEP(0, 12) CONV_KSTEP(1, 9) CONV_KSTEP(2, 6) CONV_KSTEP(3, 3) CONV_KSTEP(4, 0)
+#undef CONV_KSTEP
+#pragma unroll
+                for (int u = 0; u < CONV_NF; ++u) {
+                    const int pi = (gi * CONV_NF + u) * 16 + p;
+                    if (pi < P) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[u][r];
+                        *reinterpret_cast<bf16x4*>(stage + pi * 128 + wave * 32 + q * 8) = o;
+                    }
+                }
+            }
+        }
+        if (st + 1 < nsteps) carry_move(true);
         __syncthreads();
         // staged pixels -> global, 128 contiguous bytes per pixel (fully contiguous when C == 64)
-        const long obase = ((long)(n * Hd + row0) * Wd) * C + cb * 64 + chunk * 8;
         bf16* out = dst + obase;
-        for (int px = tid >> 3; px < P; px += 32) {
+        int ts = tid;
+        asm volatile("" : "+v"(ts));
+#pragma unroll
+        for (int k = 0; k < CONV_MAXI; ++k) {
+            const int px = (ts >> 3) + k * 32;
+            if (px >= P) break;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + px * 128 + chunk * 16);
             if (masked) {
-                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(mask_raw + obase + (long)px * C);
+                const bf16x8 raw = mraw[k];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float r = (float)raw[e];
@@ -323,7 +393,6 @@ __global__ __launch_bounds__(256) void conv3x3g_rows_kernel(const bf16* __restri
                 for (int e = 0; e < 8; ++e) { const float fv = (float)v[e]; ssum[e] += fv; ssq[e] += fv * fv; }
             }
         }
-        (void)P_full;
     }
     }
     if (stats) {
@@ -719,17 +788,19 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
         const int st = mode == 0 ? stride : 1;
         auto lds_of = [&](int rs) {
             const int nr = st == 1 ? rs + 2 : 2 * rs + 1;
-            return (size_t)nr * (rg.Ws + 2) * PSB + (size_t)rs * rg.Wd * 128 + 128 * sizeof(float);
+            return (size_t)nr * (rg.Ws + 2) * PSB + (size_t)rs * rg.Wd * 128 + 128 * sizeof(float) + CONV_NF * CONV_NG * 16 * sizeof(int);
         };
-        int cap = 196 / rg.Wd; if (cap < 1) cap = 1; if (cap > rg.Hd) cap = rg.Hd;
+        int cap = CONV_MAXP / rg.Wd; if (cap < 1) cap = 1; if (cap > rg.Hd) cap = rg.Hd;
+        // more than one step per image: the rows carried from step to step must fit their registers
+        const bool carry_ok = (st == 1 ? 2 : 1) * rg.Ws * 8 <= CONV_OVI * 256;
 
         int best = 0, best_steps = 1 << 30;
         for (int rs = cap; rs >= 1; --rs) {
-            if ((long)rs * st * rg.Ws * 8 > CONV_MAXI * 256 || lds_of(rs) > 72 * 1024) continue;
+            if ((long)rs * st * rg.Ws * 8 > CONV_MAXI * 256 || lds_of(rs) > 72 * 1024 || (rs < rg.Hd && !carry_ok) || rs * rg.Wd > CONV_MAXP) continue;
             const int steps = stes_div_up(rg.Hd, rs);
             if (steps < best_steps) { best_steps = steps; best = rs; }
         }
-        if (best == 0 && (long)st * rg.Ws * 8 <= CONV_MAXI * 256 && lds_of(1) <= 150 * 1024) best = 1;
+        if (best == 0 && (long)st * rg.Ws * 8 <= CONV_MAXI * 256 && lds_of(1) <= 150 * 1024 && (rg.Hd == 1 || carry_ok) && rg.Wd <= CONV_MAXP) best = 1;
         if (best > 0 && (long)N * (C / 64) < (1L << 31)) {
             rg.RS = best; rg.NR = st == 1 ? best + 2 : 2 * best + 1;
             rg.fd_wd = make_fastdiv(rg.Wd); rg.fd_px8 = make_fastdiv(rg.Ws * 8);

@@ -89,8 +89,11 @@ def bench_conv():
         ta = timeit(lambda: lib.call("stes_conv3x3g_fwd", lib.ptr(X), lib.ptr(wf), lib.ptr(Y), lib.ptr(sc), lib.ptr(sh), None, None, NF, Hi, Hi, Ho, Ho, stride, Cc))
         ts = timeit(lambda: lib.call("stes_conv3x3g_fwd", lib.ptr(X), lib.ptr(wf), lib.ptr(Y), None, None, lib.ptr(s1), lib.ptr(s2), NF, Hi, Hi, Ho, Ho, stride, Cc))
         td = timeit(lambda: lib.call("stes_conv3x3g_dgrad", lib.ptr(Y), lib.ptr(wd), lib.ptr(X), None, None, None, None, None, NF, Hi, Hi, Ho, Ho, stride, Cc))
+        X2 = bf(NF * Hi * Hi, Cc)
+        tm = timeit(lambda: lib.call("stes_conv3x3g_dgrad", lib.ptr(Y), lib.ptr(wd), lib.ptr(X), lib.ptr(X2), lib.ptr(sc), lib.ptr(sh), lib.ptr(s1), lib.ptr(s2),
+                                     NF, Hi, Hi, Ho, Ho, stride, Cc))
         tw = timeit(lambda: lib.call("stes_conv3x3g_wgrad", lib.ptr(Y), lib.ptr(X), lib.ptr(sc), lib.ptr(sh), lib.ptr(dw), NF, Hi, Hi, Ho, Ho, stride, Cc))
-        print(f"{name:6s} {Hi:4d} {Cc:4d} {stride} | {tf:8.1f} {byt / tf / 1e3:6.0f} (plain {tp:6.1f} affine {ta:6.1f} stats {ts:6.1f}) | {td:8.1f} {byt / td / 1e3:6.0f} | {tw:8.1f} {byt / tw / 1e3:6.0f}", flush=True)
+        print(f"{name:6s} {Hi:4d} {Cc:4d} {stride} | {tf:8.1f} {byt / tf / 1e3:6.0f} (plain {tp:6.1f} affine {ta:6.1f} stats {ts:6.1f}) | {td:8.1f} {byt / td / 1e3:6.0f} masked {tm:6.1f} | {tw:8.1f} {byt / tw / 1e3:6.0f}", flush=True)
 
 
 def bench_bn():
