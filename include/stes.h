@@ -104,11 +104,13 @@ int stes_bn_finalize(const float* sum, const float* sumsq, double count, const f
 
 /* out = relu(scale*c + shift + r), r = res_scale*res + res_shift | res | 0; optional sum / sum of
  * squares of out's first stat_c channels (the next block's gated-shift BatchNorm3d input) and a compact
- * copy slice_out [M][stat_c] of those channels.
+ * copy slice_out [M][stat_c] of those channels.  relu_bits (optional, [M][C/8] bytes): bit i of byte (m, j) = out[m, 8j+i] > 0,
+ * the ReLU mask the backward pass needs at a sixteenth of out's bytes (stes_block_in_grad's x_bits).
  * Replaces: conv3.bn + shortcut add + act3 of the timm Bottleneck, and stem bn + ReLU.   */
 int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
                          const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
-                         float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, void* stream);
+                         float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, uint8_t* relu_bits,
+                         void* stream);
 
 /* out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1), act = relu(scale*c+shift)
  * when scale is given.  Squeeze of timm SEModule, its backward, and the head's global pool.   */
@@ -166,11 +168,12 @@ int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream);
  * `out` is the gradient at the output of the layer in front; with raw1 [M][C] (the raw conv output under that layer's last
  * BatchNorm; raw2: the raw output of its shortcut conv, or NULL) the BatchNorm-backward sums of that layer are accumulated on
  * the way (s_dy += sum out, s_dyr1 += sum out*raw1, s_dyr2 += sum out*raw2; atomics, caller zeroes) and replace its
- * stes_bn_bwd_reduce pass.                                                                 */
+ * stes_bn_bwd_reduce pass.  x_bits (optional): the mask (X > 0) as written by stes_bn_act_residual's relu_bits, read
+ * instead of X (which may then be NULL).                                                   */
 int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
                        int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
                        int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
-                       float* s_dyr2, void* stream);
+                       float* s_dyr2, const uint8_t* x_bits, void* stream);
 /* Backward of global average pooling + the last block's ReLU: dZ = (da+db)/HW * (out>0). */
 int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_t* dZ, int N, int HW, int C, void* stream);
 

@@ -55,7 +55,8 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, double 
 __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
     const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
-    bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, bf16* __restrict__ slice_out, long M, int C) {
+    bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, bf16* __restrict__ slice_out, long M, int C,
+    uint8_t* __restrict__ relu_bits) {
     extern __shared__ float lds[];     // [2][stat_c]
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -89,6 +90,12 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) { o[i] = (bf16)fmaxf(v[i], 0.f); v[i] = (float)o[i]; }
         *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+        if (relu_bits) {                           // bit i: out[m, c0 + i] > 0 (what the block input gradient masks with)
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bits |= (v[i] > 0.f ? 1u : 0u) << i;
+            relu_bits[m * CH + chunk] = (uint8_t)bits;
+        }
         if (c0 < stat_c) {
             if (slice_out) *reinterpret_cast<bf16x8*>(slice_out + m * stat_c + c0) = o;
             if (stat_sum) {
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                                                             long M, int C, FastDiv fd_hw, FastDiv fd_wi,
                                                             const bf16* __restrict__ raw1, const bf16* __restrict__ raw2,
                                                             float* __restrict__ s_dy, float* __restrict__ s_dyr1,
-                                                            float* __restrict__ s_dyr2) {
+                                                            float* __restrict__ s_dyr2, const uint8_t* __restrict__ x_bits) {
     extern __shared__ float lds[];     // [3][C] when SUMS
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -432,9 +439,15 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
         }
-        load8b(X + m * C + c0, x);
+        if (x_bits) {                              // [M][C/8] bytes, bit k: X[m, c0 + k] > 0 (a sixteenth of X's bytes)
+            const unsigned bits = x_bits[m * CH + (c0 >> 3)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = x[k] > 0.f ? v[k] : 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = (bits >> k) & 1u ? v[k] : 0.f;
+        } else {
+            load8b(X + m * C + c0, x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = x[k] > 0.f ? v[k] : 0.f;
+        }
         store8b(out + m * C + c0, v);
         if (SUMS) {
             float a[8];
@@ -507,14 +520,15 @@ extern "C" int stes_bn_finalize(const float* sum, const float* sumsq, double cou
 
 extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
                                     const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
-                                    float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, void* stream) {
+                                    float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, uint8_t* relu_bits,
+                                    void* stream) {
     STES_CHECK(c && scale && shift && out && M > 0, STES_ERR_ARG, "stes_bn_act_residual: null pointer");
     STES_CHECK(C % 8 == 0 && stat_c % 8 == 0 && stat_c <= C, STES_ERR_ARG, "stes_bn_act_residual: C and stat_c must be multiples of 8");
     STES_CHECK((stat_sum == nullptr) == (stat_sumsq == nullptr), STES_ERR_ARG, "stes_bn_act_residual: stats pointers");
     STES_CHECK(stat_c == 0 || stat_sum || slice_out, STES_ERR_ARG, "stes_bn_act_residual: stat_c without an output");
     const int grid = flat_grid(M, C / 8);
     hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
-                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C);
+                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C, relu_bits);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -633,8 +647,8 @@ extern "C" int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream) {
 extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
                                   int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
                                   int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
-                                  float* s_dyr2, void* stream) {
-    STES_CHECK(dY && X && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
+                                  float* s_dyr2, const uint8_t* x_bits, void* stream) {
+    STES_CHECK(dY && (X || x_bits) && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
     STES_CHECK(C % 8 == 0 && fold % 8 == 0 && ldy % 8 == 0 && (fold == 0 || dXf), STES_ERR_ARG, "stes_block_in_grad: alignment");
     STES_CHECK(map_stride == 1 || map_stride == 2, STES_ERR_UNSUPPORTED, "stes_block_in_grad: stride must be 1 or 2");
     STES_CHECK(M <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
@@ -645,11 +659,11 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
     if (raw1)
         hipLaunchKernelGGL(block_in_grad_kernel<true>, dim3(grid), dim3(TPB), 3 * C * sizeof(float), S(stream), (const bf16*)dY, (long)ldy,
                            (const bf16*)dXf, fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C,
-                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2);
+                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2, x_bits);
     else
         hipLaunchKernelGGL(block_in_grad_kernel<false>, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf,
                            fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, fhw, fwi,
-                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, x_bits);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

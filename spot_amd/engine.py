@@ -134,6 +134,9 @@ class Block:
             self.gate = a(nm + ".gate", self.Mi * 2, F32)
         elif self.kind == "tsm":
             self.Xs = a(nm + ".Xs", self.Mi * self.cin, BF)
+        # (X > 0) as one bit per element, written by the kernel that produces X and read by this block's input gradient in
+        # place of X; the plain temporal shift masks with the shifted tensor instead (model/shift.py:55-66)
+        self.xbits = a(nm + ".xbits", self.Mi * self.cin // 8, torch.uint8) if train and self.kind != "tsm" else None
         self.c1 = a(nm + ".c1", self.Mi * self.cmid, BF)
         self.c2 = a(nm + ".c2", self.Mo * self.cmid, BF)
         self.c3 = a(nm + ".c3", self.Mo * self.cout, BF)
@@ -322,7 +325,7 @@ class Block:
         else:
             front = (e.c0, None, e.bn0.s_dy, e.bn0.s_dyr, None)
         lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
-                 p(dZp), Mi, cin, *[p(t) for t in front])
+                 p(dZp), Mi, cin, *[p(t) for t in front], p(self.xbits))
         e.side_done[par] = e.side.record_event()
         return dZp
 
@@ -454,7 +457,9 @@ class Engine:
             fold, slc = nxt.fold, nxt.Xc
             if train:
                 ssum, ssq = nxt.bng.sum, nxt.bng.sumsq
-        lib.call("stes_bn_act_residual", p(c), p(bn.scale), p(bn.shift), p(res), p(rs), p(rb), p(out), p(ssum), p(ssq), fold, p(slc), M, Cc)
+        bits = nxt.xbits if nxt is not None and train else None
+        lib.call("stes_bn_act_residual", p(c), p(bn.scale), p(bn.shift), p(res), p(rs), p(rb), p(out), p(ssum), p(ssq), fold, p(slc), M, Cc,
+                 p(bits))
 
     # ------------------------------------------------------------------ flat parameters
     def _flatten(self):

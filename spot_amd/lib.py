@@ -72,7 +72,7 @@ _SIGS = {
     "stes_gemm": [_P, _P],
     "stes_wgrad": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
-    "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P],
+    "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
     "stes_clip_gate_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
@@ -82,7 +82,7 @@ _SIGS = {
     "stes_bn_bwd_reduce": [_P, _P],
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
     "stes_bn_bwd_apply": [_P, _P],
-    "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P],
+    "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_pack_conv3x3g": [_P, _P, _P, _I32, _I32, _P],
     "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
@@ -170,9 +170,11 @@ _KERNEL_OF = {
     "stes_conv3x3g_dgrad": ("conv3x3g_rows_kernel / conv3x3g_dgrad2_kernel (input gradient)",
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
     "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
-    # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums...): every operand once
+    # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums..., x_bits): every operand once (the
+    # mask as X, 2 bytes per element, or as bits, an eighth of a byte)
     "stes_block_in_grad": (lambda a: "block_in_grad_kernel<%s>" % ("true" if a[14] is not None else "false"),
-                           lambda a: 2 * a[12] * a[13] * (3 + (a[14] is not None) + (a[15] is not None))
+                           lambda a: 2 * a[12] * a[13] * (2 + (a[14] is not None) + (a[15] is not None))
+                           + (a[12] * a[13] // 8 if a[19] is not None else 2 * a[12] * a[13])
                            + (2 * a[12] * a[13] // (a[5] * a[5]) if a[4] is not None else 0)),
 }
 

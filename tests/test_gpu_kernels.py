@@ -157,10 +157,13 @@ def test_bn_finalize_and_act_residual():
     out = torch.empty(M, Cc, dtype=BF, device="cuda")
     st1 = torch.zeros(16, device="cuda"); st2 = torch.zeros(16, device="cuda")
     slc = torch.zeros(M, 16, dtype=BF, device="cuda")
+    rbits = torch.zeros(M, Cc // 8, dtype=torch.uint8, device="cuda")
     lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), lib.ptr(dev(res)), None, None, lib.ptr(out),
-             lib.ptr(st1), lib.ptr(st2), 16, lib.ptr(slc), M, Cc)
+             lib.ptr(st1), lib.ptr(st2), 16, lib.ptr(slc), M, Cc, lib.ptr(rbits))
     torch.cuda.synchronize()
     close(out, ref.detach(), 1e-2, 1e-2)
+    want = ((out.view(M, Cc // 8, 8) > 0).to(torch.int32) << torch.arange(8, dtype=torch.int32, device="cuda")).sum(-1).to(torch.uint8)
+    assert torch.equal(rbits, want)
     close(rmd, bn.running_mean, 1e-5, 1e-5); close(rvd, bn.running_var, 1e-4, 1e-5)
     close(st1, out.float()[:, :16].sum(0), 1e-4, 1e-3); close(st2, (out.float()[:, :16] ** 2).sum(0), 1e-4, 1e-3)
     assert torch.equal(slc, out[:, :16])
@@ -171,7 +174,7 @@ def test_bn_finalize_and_act_residual():
     with torch.no_grad():
         bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
         ref = torch.relu(bn(c.float()))
-    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), None, None, None, lib.ptr(out), None, None, 0, None, M, Cc)
+    lib.call("stes_bn_act_residual", lib.ptr(dev(c)), lib.ptr(scale), lib.ptr(shift), None, None, None, lib.ptr(out), None, None, 0, None, M, Cc, None)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
 
@@ -291,12 +294,12 @@ def test_block_in_grad_and_pool_bwd():
     out = torch.empty(M, Cc, dtype=BF, device="cuda")
     d = dev
     lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
-             None, None, None, None, None)
+             None, None, None, None, None, None)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
     ref = (torch.cat([dXf.float(), dY.float()[:, fold:]], 1) + dY.float()) * (X.float() > 0)
     lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
-             None, None, None, None, None)
+             None, None, None, None, None, None)
     torch.cuda.synchronize()
     close(out, ref, 1e-2, 1e-2)
     # the same with the BatchNorm-backward sums of the layer in front taken on the way out (of the rounded values)
@@ -304,7 +307,7 @@ def test_block_in_grad_and_pool_bwd():
     r1, r2 = bfr(M, Cc, g=g), bfr(M, Cc, g=g)
     sums = [torch.zeros(Cc, device="cuda") for _ in range(3)]
     lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(dY)), 1, Hi, Wi, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
-             lib.ptr(d(r1)), lib.ptr(d(r2)), *[lib.ptr(t) for t in sums])
+             lib.ptr(d(r1)), lib.ptr(d(r2)), *[lib.ptr(t) for t in sums], None)
     torch.cuda.synchronize()
     assert torch.equal(out, plain)
     o = out.float().cpu()
@@ -313,14 +316,24 @@ def test_block_in_grad_and_pool_bwd():
     close(sums[2], (o * r2.float()).sum(0), 1e-4, 1e-3)
     sums = [torch.zeros(Cc, device="cuda") for _ in range(2)]
     lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out), M, Cc,
-             lib.ptr(d(r1)), None, lib.ptr(sums[0]), lib.ptr(sums[1]), None)
+             lib.ptr(d(r1)), None, lib.ptr(sums[0]), lib.ptr(sums[1]), None, None)
     torch.cuda.synchronize()
     o = out.float().cpu()
     close(sums[0], o.sum(0), 1e-4, 1e-3)
     close(sums[1], (o * r1.float()).sum(0), 1e-4, 1e-3)
+    # the mask as one bit per element (what stes_bn_act_residual writes beside X) instead of X itself
+    bits = (X.float() > 0).view(M, Cc // 8, 8).to(torch.int32)
+    bits = (bits << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    keep, sums2 = out.clone(), [torch.zeros(Cc, device="cuda") for _ in range(2)]
+    out.zero_()
+    lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, None, lib.ptr(out), M, Cc,
+             lib.ptr(d(r1)), None, lib.ptr(sums2[0]), lib.ptr(sums2[1]), None, lib.ptr(d(bits)))
+    torch.cuda.synchronize()
+    assert torch.equal(out, keep)
+    close(sums2[0], sums[0], 1e-5, 1e-4); close(sums2[1], sums[1], 1e-5, 1e-4)        # atomics: order varies
     with pytest.raises(lib.StesError):
         lib.call("stes_block_in_grad", lib.ptr(d(dY)), Cc, lib.ptr(d(dXf)), fold, lib.ptr(d(Dsc)), 2, Ho, Wo, Hi, Wi, lib.ptr(d(X)), lib.ptr(out),
-                 M, Cc, lib.ptr(d(r1)), None, None, None, None)
+                 M, Cc, lib.ptr(d(r1)), None, None, None, None, None)
     da, db = torch.randn(N, Cc, generator=g), torch.randn(N, Cc, generator=g)
     ref = ((da + db)[:, None] / (Hi * Wi) * (X.float().view(N, Hi * Wi, Cc) > 0)).reshape(M, Cc)
     lib.call("stes_pool_bwd", lib.ptr(d(da)), lib.ptr(d(db)), lib.ptr(d(X)), lib.ptr(out), N, Hi * Wi, Cc)
