@@ -22,7 +22,7 @@ CONVS = [("s1", 112, 64, 2), ("s2.b1", 56, 128, 2), ("s2", 28, 128, 1), ("s3.b1"
 GSMS = [("s1.b1", 112, 8), ("s2.b1", 56, 16), ("s2", 28, 32), ("s3", 14, 80), ("s4.b2", 7, 192)]
 
 
-def timeit(fn, reps=5):
+def timeit(fn, reps=int(os.environ.get('REPS', '5'))):
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
