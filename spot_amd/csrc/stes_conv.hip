@@ -667,10 +667,11 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
                                                              int stride, int C, int n_items, FastDiv fd_tiles, FastDiv fd_tw,
                                                              FastDiv fd_iw) {
     // one LDS block: staging tiles while walking items, then re-used to lay the result out for coalesced atomics
-    __shared__ __attribute__((aligned(16))) unsigned char smem[9216 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * 16 * 2 + 4 * MAX_HALO * 16 * 2];
+    static_assert(sizeof(smem) >= 4608 * 4, "the result layout of two groups must fit the staging tiles");
     bf16* Pt = reinterpret_cast<bf16*>(smem);                     // [4 groups][32 px (rho)][16]
     bf16* It = reinterpret_cast<bf16*>(smem + 4 * 32 * 16 * 2);    // [4 groups][MAX_HALO][16]
-    float* red = reinterpret_cast<float*>(smem);                  // [4 groups][16 co][16 ci][9]
+    float* red = reinterpret_cast<float*>(smem);                  // [2 groups][16 co][16 ci][9]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int gq = blockIdx.y;
@@ -728,8 +729,13 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
             }
         }
     };
-    if ((int)blockIdx.x < n_items) fetch(blockIdx.x);
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // Neighbouring items are neighbouring tiles of one image and share their halo pixels.  Workgroups go to the 8 XCDs (each
+    // with its own L2) round-robin by index, so the index is permuted: XCD j walks a contiguous eighth of every round of items
+    // and the shared pixels come out of its L2 instead of being fetched from memory once per tile.
+    int first = blockIdx.x;
+    if ((gridDim.x & 7) == 0) first = (blockIdx.x >> 3) + (blockIdx.x & 7) * (gridDim.x >> 3);
+    if (first < n_items) fetch(first);
+    for (int item = first; item < n_items; item += gridDim.x) {
         *reinterpret_cast<bf16x8*>(&Pt[(cgrp * 32 + rho32(tid >> 3)) * 16 + chalf * 8]) = r_out;
 #pragma unroll
         for (int k = 0; k < MAXH; ++k) {
@@ -763,14 +769,21 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
         }
         __syncthreads();
     }
-    // result -> LDS in the checkpoint layout [co][ci][tap] of the 64 channels of this workgroup, then contiguous atomics
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * 16 + fq * 4 + r) * 16 + fr) * 9 + t] = acc[t][r];
-    __syncthreads();
+    // result -> LDS in the checkpoint layout [co][ci][tap] of the 64 channels of this workgroup, then contiguous atomics; two
+    // groups at a time, so that this layout needs no more LDS than the staging tiles (24 KiB: six workgroups per CU)
     float* dst = dw + (long)gq * 9216;
-    for (int i = tid; i < 9216; i += 256) atomicAdd(dst + i, red[i]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((wave >> 1) == h) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave & 1) * 16 + fq * 4 + r) * 16 + fr) * 9 + t] = acc[t][r];
+        }
+        __syncthreads();
+        for (int i = tid; i < 4608; i += 256) atomicAdd(dst + h * 4608 + i, red[i]);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ stem im2col
@@ -1018,8 +1031,16 @@ extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, con
     const int n_items = N * th * tw;
     const int gy = C / 64;
     int gx = n_items;
-    const int cap = 2048 / gy > 1 ? 2048 / gy : 1;
+    // exactly one resident set of workgroups (three per CU, by registers): measured over grid sizes, the time has a sharp
+    // minimum there (364 us at 768 workgroups, 494 at 832, 396 at 640 for 112 x 112 x 64) -- a second, partial round runs on a
+    // part-empty GPU, and every workgroup ends with 36 KiB of atomics into the same weight gradient
+    static const int resident = [] {
+        int occ = 0;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv3x3g_wgrad_kernel, 256, 0) == hipSuccess && occ > 0 ? occ : 1;
+    }();
+    const int cap = 256 * resident / gy > 1 ? 256 * resident / gy : 1;
     if (gx > cap) gx = cap;
+    if (gx > 8) gx &= ~7;                      // a multiple of 8: see the kernel's item permutation
     const int IW = (TW - 1) * stride + 3;
     hipLaunchKernelGGL(conv3x3g_wgrad_kernel, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)dout, (const bf16*)in, in_scale, in_shift,
                        dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, make_fastdiv(th * tw), make_fastdiv(tw), make_fastdiv(IW));

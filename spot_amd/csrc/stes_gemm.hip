@@ -593,7 +593,8 @@ __global__ __launch_bounds__(512) void wgrad_strip_kernel(const stes_wgrad_args 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int qhalf = blockIdx.x & 1, mblk = blockIdx.x >> 1;
+    // the two halves of a row chunk share blockIdx % 8, one XCD's L2: dY is then fetched from memory once, not once per half
+    const int qhalf = (blockIdx.x >> 3) & 1, mblk = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
     const long m_begin = (long)mblk * m_chunk;
     const long m_end = (m_begin + m_chunk < p.M) ? m_begin + m_chunk : p.M;
     if (m_begin >= m_end) return;
@@ -857,7 +858,7 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
                 return ok;
             }();
             if (raised) {
-                const dim3 grid(mb * 2), block(512);
+                const dim3 grid(stes_div_up(mb, 8) * 16), block(512);       // (chunk, half) -> block: see the kernel
                 hipStream_t st = (hipStream_t)stream;
                 if (pro && slab) hipLaunchKernelGGL((wgrad_strip_kernel<true, true>), grid, block, lds, st, *a, (int)chunk, dv);
                 else if (pro) hipLaunchKernelGGL((wgrad_strip_kernel<true, false>), grid, block, lds, st, *a, (int)chunk, dv);

@@ -166,8 +166,10 @@ def _conv_bytes(a):
 # entry point -> (kernel name, algorithmic bytes of one call): every operand read once, every result written once
 _KERNEL_OF = {
     "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
-    "stes_conv3x3g_fwd": ("conv3x3g_rows_kernel (forward)", _conv_bytes),
-    "stes_conv3x3g_dgrad": ("conv3x3g_rows_kernel / conv3x3g_dgrad2_kernel (input gradient)",
+    # (names as a kernel trace prints them, for the shapes of the named configuration: all of them fit the LDS-window kernels)
+    "stes_conv3x3g_fwd": (lambda a: "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
+    "stes_conv3x3g_dgrad": (lambda a: "conv3x3g_rows_kernel<1, true>" if a[-2] == 1 else
+                            "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
     "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
     # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums..., x_bits): every operand once (the

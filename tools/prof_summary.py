@@ -13,8 +13,11 @@ def short(name):
     if m:       # anonymous-namespace kernel with __bf16 parameters, which llvm-cxxfilt leaves mangled
         n = int(m.group(1))
         base, rest = name[m.end():m.end() + n], name[m.end() + n:]
-        t = re.match(r"I((?:Li\d+E)+)E", rest)
-        return base + ("<" + ", ".join(re.findall(r"Li(\d+)E", t.group(1))) + ">" if t else "")
+        t = re.match(r"I((?:L[ib]\d+E)+)E", rest)
+        if not t:
+            return base
+        args = [v if k == "i" else ("true" if v == "1" else "false") for k, v in re.findall(r"L([ib])(\d+)E", t.group(1))]
+        return base + "<" + ", ".join(args) + ">"
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([A-Za-z0-9_:]+(?:<[^>]*>)?)", name)
