@@ -812,10 +812,17 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     const bool wide = a->N > 64 && (long)m_tiles * stes_div_up(a->N, 128) >= 300 && !(a->N % 128 != 0 && a->N % 64 == 0);
     const int bn = wide ? 128 : 64;
     const int n_tiles = stes_div_up(a->N, bn);
+    // Workgroups walk row tiles `m_slots` apart.  With more tiles than fit the GPU at once the grid is one resident set, not
+    // more: further workgroups would run as a partial round beside an emptying GPU.
+    static const int res128 = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<128>, 256, 0) == hipSuccess && n > 0 ? n : 1; }();
+    static const int res64 = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<64>, 256, 0) == hipSuccess && n > 0 ? n : 1; }();
+    const int resident = 256 * (wide ? res128 : res64);
     int m_slots = m_tiles;
-    const int cap = 2048 / n_tiles > 8 ? 2048 / n_tiles : 8;
-    if (m_slots > cap) m_slots = cap;
-    const int slot_groups = stes_div_up(m_slots, 8);
+    int slot_groups = stes_div_up(m_slots, 8);
+    if ((long)slot_groups * 8 * n_tiles > resident) {
+        slot_groups = resident / (8 * n_tiles) > 1 ? resident / (8 * n_tiles) : 1;
+        m_slots = slot_groups * 8;
+    }
     const int grid = slot_groups * n_tiles * 8;
     if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
     else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
