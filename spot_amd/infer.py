@@ -28,6 +28,26 @@ def window_batches(n_frames, clip_len, batch_size, rank=0, world=1):
     return [b for i, b in enumerate(batches) if i % world == rank]
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def pad_last_window(clip, clip_len, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """A window that runs past the end of the video is filled up with black frames.  The reference pads with zero frames
+    BEFORE its Resize/ToDtype/Normalize transform (VideoFrameSlidingDataset, inference_on_mp4.py:523-524), so a padded frame of
+    an already normalised float clip holds (0 - mean) / std per channel; a uint8 clip is padded with zero bytes (the stem
+    kernel normalises them).  Padded frames reach real ones through the gated shift and the bidirectional GRU."""
+    n = clip_len - clip.shape[0]
+    if n <= 0:
+        return clip
+    pad = torch.zeros((n,) + tuple(clip.shape[1:]), dtype=clip.dtype, device=clip.device)
+    if clip.dtype.is_floating_point:
+        c = clip.shape[1]
+        m = torch.tensor(mean[:c], dtype=torch.float32, device=clip.device)
+        sd = torch.tensor(std[:c], dtype=torch.float32, device=clip.device)
+        pad = pad + (-m / sd).to(clip.dtype).view(1, c, 1, 1)
+    return torch.cat([clip, pad], 0)
+
+
 def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=True, rank=0, world=1, video="video",
                   gather=None):
     """model: E2EModel; frames [n_frames, C, H, W]: float tensor (normalised; host or device), uint8 tensor (decoded), or a
@@ -41,9 +61,8 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
             clip = frames[s:s + clip_len]
             if not torch.is_tensor(clip):          # a numpy array or read-only memory map: copy the window
                 clip = torch.from_numpy(np.array(clip))
-            if clip.shape[0] < clip_len:       # zero-pad the last window
-                pad = torch.zeros((clip_len - clip.shape[0],) + tuple(clip.shape[1:]), dtype=clip.dtype, device=clip.device)
-                clip = torch.cat([clip, pad], 0)
+            if clip.shape[0] < clip_len:
+                clip = pad_last_window(clip, clip_len, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
             clips.append(clip)
         batch = torch.stack(clips, 0)
         out = model.predict(batch)

@@ -165,7 +165,11 @@ def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag
         assert len(quiet) >= 10 and min(r[2] for r in sig) > 0.8, sorted(sig, key=lambda r: r[2])[:4]
     assert np.percentile(cosines, 5) > 0.75, sorted(cosines)[:8]
     print("ours/yardstick: median %.2f  p95 %.2f  max %.2f over %d tensors" % (np.median(ratios), np.percentile(ratios, 95), ratios.max(), len(ratios)))
-    # one noise realisation per run (the fp32 atomics reorder), so the criterion is on the distribution over the 250+ tensors
+    # One noise realisation per run: the order of the fp32 atomics in the BatchNorm sums differs from run to run, that moves
+    # pre-activations in the last bits, and on an 8-frame batch the ReLU masks that flip with them move backbone gradients by
+    # 23-32 % between two runs of the SAME step -- measured identically with the weight-gradient kernels on the side stream
+    # and in program order (tests/test_gpu_dp_world2.py), so it is not a stream hazard.  The criterion is therefore on the
+    # distribution over the 250+ tensors.
     assert np.median(ratios) < 1.3 and np.percentile(ratios, 95) < 2.0 and ratios.max() < 3.5
     report.sort(reverse=True)
     print("largest gradient deviations (ours vs fp32, bf16-oracle vs fp32, cosine, name):")

@@ -198,6 +198,14 @@ def test_sliding_window_accumulator_and_sharding():
     acc.add(0, a, rng.rand(64, 2).astype(np.float32)); acc.add(64, b, rng.rand(64, 2).astype(np.float32))
     sc, loc = acc.finish()
     assert np.array_equal(sc[:64], a) and np.array_equal(sc[64:], b[:36])
+    # the last window's black frames: zero bytes for decoded input, (0 - mean) / std for input that is already normalised
+    # (the reference pads before its Normalize transform, inference_on_mp4.py:523-524)
+    u8 = infer.pad_last_window(torch.full((3, 3, 2, 2), 7, dtype=torch.uint8), 5)
+    assert u8.shape[0] == 5 and int(u8[3:].max()) == 0 and int(u8[:3].min()) == 7
+    fl = infer.pad_last_window(torch.ones(3, 3, 2, 2), 5)
+    want = torch.tensor([-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225])
+    assert fl.shape[0] == 5 and torch.allclose(fl[3:, :, 0, 0], want.expand(2, 3)) and torch.equal(fl[:3], torch.ones(3, 3, 2, 2))
+    assert infer.pad_last_window(fl, 5) is fl
 
 
 def test_roofline_accounting_matches_the_layer_table():
