@@ -1268,10 +1268,19 @@ extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const f
     const int nct = (half + 15) / 16;
     const int pos = nct == 1 ? 64 : 32;
     const long n_chunks = (gm.M + pos - 1) / pos;
-    long gx = (n_chunks + 31) / 32; if (gx > 1024) gx = 1024;       // >= 8 chunks per wave
-    const dim3 grid((int)gx);
     const FastDiv fd_nch8 = make_fastdiv(gm.fold / 8);
-#define LAUNCH_WG(N, P) hipLaunchKernelGGL((gsm_bwd_wgrad_kernel<N, P>), grid, dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks, fd_nch8)
+    // >= 8 chunks per wave, and never more workgroups than are resident at once (a partial second round of a grid-stride
+    // kernel runs on a part-empty GPU; the 49 KiB and 132 registers of the 64-position form allow three per CU)
+#define LAUNCH_WG(N, P)                                                                                                            \
+    do {                                                                                                                           \
+        static const int resident = [] {                                                                                           \
+            int n = 0;                                                                                                             \
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gsm_bwd_wgrad_kernel<N, P>, 256, 0) == hipSuccess && n > 0 ? 256 * n : 256; \
+        }();                                                                                                                       \
+        long gx = (n_chunks + 31) / 32;                                                                                            \
+        if (gx > resident) gx = resident;                                                                                          \
+        hipLaunchKernelGGL((gsm_bwd_wgrad_kernel<N, P>), dim3((int)gx), dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks, fd_nch8); \
+    } while (0)
     switch (nct) {
         case 1: LAUNCH_WG(1, 64); break;
         case 2: LAUNCH_WG(2, 32); break;
