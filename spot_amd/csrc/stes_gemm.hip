@@ -787,10 +787,13 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
                STES_ERR_ARG, "stes_gemm: the BatchNorm-backward prologue needs alpha/beta/delta and excludes the other prologues");
     STES_CHECK(bnb || !a->a_out, STES_ERR_ARG, "stes_gemm: a_out without a_raw");
     // tall-and-skinny bf16 layers with small K and N: weights resident in LDS, rows streamed (stes_gemm_stream.hip)
+    STES_CHECK(!a->wg_dw || (bnb && a->wg_q && !a->a_out && a->wg_ldq >= a->N && a->wg_lddw >= a->N && a->wg_k0 % 8 == 0 && (a->wg_k0 == 0 || a->wg_q0)),
+               STES_ERR_ARG, "stes_gemm: the fused weight gradient needs the BatchNorm-backward prologue, Q and no a_out");
     if (stes_gemm_stream(a, stream)) {
         STES_LAUNCH_CHECK();
         return STES_OK;
     }
+    STES_CHECK(!a->wg_dw, STES_ERR_UNSUPPORTED, "stes_gemm: the fused weight gradient is built for K = 64, N = 32 on the streaming kernel");
     RowDivs dv;
     dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
     dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);

@@ -33,10 +33,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // is bf16(alpha*A + beta*a_raw + delta) -- what stes_bn_bwd_apply would have written; it is written here too (a_out, by the
 // workgroups of column slice 0) for the weight-gradient kernel, which saves that kernel's pass and one read of its result.
 // NK = K/32 k-steps per tile, TA tiles in the ring, J 16-row fragments per tile.
-template <int NI, int WAVES, int PRO, int NK, int TA, int J>   // NB = 16*NI columns per workgroup
-__global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
-                                                                 StreamDivs dv) {
+// WG: the layer's weight gradient dW[K][N] += pro(A)^T Q in the same pass (PRO 2, J = 2, one column slice).  A tile's 32 rows are
+// one MFMA k-step of the transposed product: the transformed operand and the Q tile go to a wave-private LDS area as
+// [32 rows][16 columns] sub-tiles (rows permuted by rho32 like the weight-gradient kernels' tiles) and come back through
+// ds_read_b64_tr_b16 as fragments with the rows in the contraction dimension; K/16 x N/16 accumulator tiles per wave, added to
+// wg_dw with atomics when the wave has walked its tiles.  The transformed operand then never travels through memory.
+__device__ __forceinline__ int rho32(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+__device__ __forceinline__ int wg_dest(int c, int fold) {    // within-group channel interleave of the gated shift (model/shift.py:124-128)
+    const int half = fold >> 1, quarter = fold >> 2;
+    const int g = c / half, rem = c - g * half;
+    const int i = rem / quarter, j = rem - i * quarter;
+    return g * half + 2 * j + i;
+}
+
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG>   // NB = 16*NI columns per workgroup
+__device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int row_tiles, int n_slices, int m_slots, const StreamDivs& dv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(!WG || (PRO == 2 && J == 2), "the fused weight gradient rides on the BatchNorm-backward form with 32-row tiles");
     constexpr bool AFF = PRO == 1, BNB = PRO == 2;
     constexpr int NB = NI * 16, TR = 16 * J, K = NK * 32;
     constexpr int CPR = NB / 8;                 // 16-byte chunks per output row
@@ -57,6 +70,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     float* sh_s = sc_s + K;
     float* de_s = sh_s + K;                     // BNB: sc_s = alpha, sh_s = beta, de_s = delta
     float* red = de_s + K;                      // [2][NB]
+    constexpr int WG_PSUB = K / 16, WG_QSUB = NB / 16;                         // [32][16] bf16 sub-tiles (1 KiB each) of pro(A) and of Q
+    unsigned char* wgl = reinterpret_cast<unsigned char*>(red + 2 * NB) + wave * (WG_PSUB + WG_QSUB) * 1024;
     // AFF: this wave's copy of the gate rows of the (at most two) images its current tile touches, or ones without a gate.
     // It lives in the wave's output staging buffer: the gate is read in the k loop, the staging buffer in the tile epilogue.
     float* gl = reinterpret_cast<float*>(stage);
@@ -111,6 +126,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     };
     bf16x8 ring[TA][NK][J];
     bf16x8 ring_r[BNB ? TA : 1][BNB ? NK : 1][J];
+    // WG: Q tile of 32 rows x NB columns = 32 * NB/8 16-byte chunks, NB/16 per lane; chunk c of a lane is (row, 8 columns)
+    constexpr int WG_QC = WG ? NB / 16 : 1;
+    bf16x8 ring_q[WG ? TA : 1][WG_QC];
+    const bf16* fq_src[WG_QC];
+    f32x4 accw[WG ? WG_PSUB : 1][WG ? WG_QSUB : 1];
+    if constexpr (WG) {
+#pragma unroll
+        for (int a = 0; a < WG_PSUB; ++a)
+#pragma unroll
+            for (int b = 0; b < WG_QSUB; ++b) accw[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto q_rows_of = [&](long tile) {
+        if constexpr (WG) {
+#pragma unroll
+            for (int c = 0; c < WG_QC; ++c) {
+                const int id = lane + 64 * c, row = id / (NB / 8), cc = id % (NB / 8);
+                long m = tile * TR + row;
+                if (m >= M) m = M - 1;
+                fq_src[c] = (cc * 8 < p.wg_k0) ? (const bf16*)p.wg_q0 + m * p.wg_ldq0 + cc * 8 : (const bf16*)p.wg_q + m * p.wg_ldq + cc * 8;
+            }
+        }
+    };
+    auto q_refill = [&](auto tc) {
+        if constexpr (WG) {
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int c = 0; c < WG_QC; ++c) ring_q[t][c] = *reinterpret_cast<const bf16x8*>(fq_src[c]);
+        }
+    };
     // slot (t, ks) <- k-step ks of the tile whose pointers are current
     auto refill = [&](auto tc, auto kc) {
         constexpr int t = decltype(tc)::value, ks = decltype(kc)::value;
@@ -190,6 +234,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
                 fb[j] = pack8(f);
                 const long m = c_tile * TR + j * 16 + fr;
                 if (p.a_out && slice == 0 && m < M) *reinterpret_cast<bf16x8*>(p.a_out + m * p.lda_out + k) = fb[j];
+                if constexpr (WG) {               // sub-tile k/16, row rho32(j*16+fr), column half (k/8)&1; rows past the end add nothing
+                    *reinterpret_cast<bf16x8*>(wgl + (k >> 4) * 1024 + rho32(j * 16 + fr) * 32 + ((k >> 3) & 1) * 16) = m < M ? fb[j] : zero8();
+                }
             }
         }
         if constexpr (AFF) {
@@ -223,6 +270,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     static_for<0, TA>([&](auto tc) {
         rows_of(c_tile + decltype(tc)::value * tstride);
         static_for<0, NK>([&](auto kc) { refill(tc, kc); });
+        q_rows_of(c_tile + decltype(tc)::value * tstride);
+        q_refill(tc);
     });
     gate_fetch(c_tile);
     gate_commit(c_tile);
@@ -231,6 +280,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
         static_for<0, TA>([&](auto tc) {
             // tiles past the end (the last round of a ring of several tiles) run with every row masked
             rows_of(c_tile + TA * tstride);                         // what this tile's slots are refilled with
+            if constexpr (WG) {                                     // this tile's Q rows -> LDS sub-tiles, the slot refilled
+#pragma unroll
+                for (int c = 0; c < WG_QC; ++c) {
+                    const int id = lane + 64 * c, row = id / (NB / 8), cc = id % (NB / 8);
+                    *reinterpret_cast<bf16x8*>(wgl + (WG_PSUB + (cc >> 1)) * 1024 + rho32(row) * 32 + (cc & 1) * 16) = ring_q[decltype(tc)::value][c];
+                }
+                q_rows_of(c_tile + TA * tstride);
+                q_refill(tc);
+            }
             gate_fetch(c_tile + tstride);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -257,6 +315,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
                     for (int j = 0; j < J; ++j) fbc[j] = fbn[j];
                 }
             });
+            if constexpr (WG) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // fragment of a [32][16] sub-tile with the 32 rows as the contraction dimension (as conv3x3g_wgrad_kernel)
+                const int px_lo = 8 * fq + (fr >> 2), cc4 = 4 * (fr & 3);
+                const int o_lo = rho32(px_lo) * 32 + cc4 * 2, o_hi = rho32(px_lo + 4) * 32 + cc4 * 2;
+                auto frag_of = [&](int sub) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(wgl + sub * 1024 + o_lo));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(wgl + sub * 1024 + o_hi));
+                    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                bf16x8 qf[WG_QSUB];
+#pragma unroll
+                for (int b = 0; b < WG_QSUB; ++b) qf[b] = frag_of(WG_PSUB + b);
+#pragma unroll
+                for (int a = 0; a < WG_PSUB; ++a) {
+                    const bf16x8 pf = frag_of(a);
+#pragma unroll
+                    for (int b = 0; b < WG_QSUB; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[b], accw[a][b], 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             // ---- tile done: through the staging buffer, 16 rows at a time
             const long m_base = c_tile * TR;
 #pragma unroll
@@ -292,6 +372,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
             gate_commit(c_tile);
         });
     }
+    if constexpr (WG) {                  // D[k][n]: lane column n = fr, rows k = 4 fq + r
+#pragma unroll
+        for (int a = 0; a < WG_PSUB; ++a)
+#pragma unroll
+            for (int b = 0; b < WG_QSUB; ++b) {
+                const int n = b * 16 + fr;
+                const int nd = n < p.wg_perm_fold ? wg_dest(n, p.wg_perm_fold) : n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(p.wg_dw + (long)(a * 16 + fq * 4 + r) * p.wg_lddw + nd, accw[a][b][r]);
+            }
+    }
     if (stats) {
         if (o_active) {
 #pragma unroll
@@ -305,38 +396,63 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm
     }
 }
 
+template <int NI, int WAVES, int PRO, int NK, int TA, int J>
+__global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
+                                                                 StreamDivs dv) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false>(p, row_tiles, n_slices, m_slots, dv);
+}
+
+// the same with the layer's weight gradient in the same pass (see gemm_stream_body)
+template <int NI, int WAVES, int PRO, int NK, int TA, int J>
+__global__ __launch_bounds__(WAVES * 64, 2) void gemm_stream_wg_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
+                                                                    StreamDivs dv) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, true>(p, row_tiles, n_slices, m_slots, dv);
+}
+
 // Workgroups of one instantiation resident per CU at a given dynamic LDS size (queried once; the LDS size is fixed by
 // the template arguments).  Entry points may be called from any host thread: the cache sits behind a mutex.
-template <int NI, int WAVES, int PRO, int NK, int TA, int J>
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG>
 static int stream_residency(size_t lds) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     static int per_cu = 0;
     if (per_cu == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         int n = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>, WAVES * 64, lds) != hipSuccess || n < 1)
-            n = 1;
+        hipError_t e;
+        if constexpr (WG) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>, WAVES * 64, lds);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>, WAVES * 64, lds);
+        }
+        if (e != hipSuccess || n < 1) n = 1;
         per_cu = n;
     }
     return per_cu;
 }
 
-template <int NI, int WAVES, int PRO, int NK, int TA, int J>
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG = false>
 static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs& dv) {
     constexpr int NB = NI * 16, K = NK * 32;
-    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + 2 * NB) * sizeof(float);
+    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + 2 * NB) * sizeof(float) +
+                       (WG ? (size_t)WAVES * (K / 16 + NB / 16) * 1024 : 0);
     const int n_slices = a->N / NB;
     const int row_tiles = stes_div_up(a->M, 16 * J);
-    const int per_cu = stream_residency<NI, WAVES, PRO, NK, TA, J>(lds);
+    const int per_cu = stream_residency<NI, WAVES, PRO, NK, TA, J, WG>(lds);
     // one resident set of workgroups: further ones would only add statistics atomics and weight-slice loads
     int m_slots = stes_div_up(row_tiles, WAVES);
     const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;
     if (m_slots > cap) m_slots = cap;
     const int grid = stes_div_up(m_slots, 8) * n_slices * 8;
-    hipLaunchKernelGGL((gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
-                       m_slots, dv);
+    if constexpr (WG)
+        hipLaunchKernelGGL((gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
+                           m_slots, dv);
+    else
+        hipLaunchKernelGGL((gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
+                           m_slots, dv);
 }
 
 template <int NI, int WAVES, int PRO>
@@ -344,11 +460,15 @@ static bool launch_k(const stes_gemm_args* a, hipStream_t stream, const StreamDi
     // ring: K = 320 one 16-row tile (10 k-steps) ahead; K = 128 one 32-row tile; K = 64 two; K = 32 four
     switch (a->K) {
         case 320:
+            if (a->wg_dw) return false;
             // (with the gate prologue the two gate rows must fit the wave's staging buffer: slices of 128 columns and more)
             if constexpr (PRO == 0) { launch<NI, WAVES, PRO, 10, 2, 1>(a, stream, dv); return true; } else if constexpr (PRO != 1 || NI >= 8) { launch<NI, WAVES, PRO, 10, 1, 1>(a, stream, dv); return true; } else return false;
-        case 128: launch<NI, WAVES, PRO, 4, 1, 2>(a, stream, dv); return true;
-        case 64: launch<NI, WAVES, PRO, 2, 2, 2>(a, stream, dv); return true;
-        case 32: if constexpr (PRO != 2) { launch<NI, WAVES, PRO, 1, 4, 2>(a, stream, dv); return true; } else return false;
+        case 128: if (a->wg_dw) return false; launch<NI, WAVES, PRO, 4, 1, 2>(a, stream, dv); return true;
+        case 64:
+            if constexpr (PRO == 2 && NI == 2) { if (a->wg_dw) { launch<NI, WAVES, PRO, 2, 2, 2, true>(a, stream, dv); return true; } }
+            if (a->wg_dw) return false;
+            launch<NI, WAVES, PRO, 2, 2, 2>(a, stream, dv); return true;
+        case 32: if (a->wg_dw) return false; if constexpr (PRO != 2) { launch<NI, WAVES, PRO, 1, 4, 2>(a, stream, dv); return true; } else return false;
         default: return false;
     }
 }

@@ -38,7 +38,9 @@ GemmArgs = _struct("GemmArgs", [
     ("relu_mask", _P), ("ldmask", _I64),
     ("C0", _P), ("ldc0", _I64), ("n_split", _I32),
     ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32),
-    ("a_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("a_out", _P), ("lda_out", _I64)])
+    ("a_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("a_out", _P), ("lda_out", _I64),
+    ("wg_q", _P), ("wg_ldq", _I64), ("wg_q0", _P), ("wg_ldq0", _I64), ("wg_k0", _I32), ("wg_perm_fold", _I32),
+    ("wg_dw", _P), ("wg_lddw", _I64)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -229,6 +231,11 @@ def _stream_slice(N):
 _RING = {320: (10, 1, 1), 128: (4, 1, 2), 64: (2, 2, 2), 32: (1, 4, 2)}       # K -> (k-steps, tiles in the ring, 16-row fragments)
 
 
+def gemm_fuses_wgrad(M, N, K):
+    """Shapes for which stes_gemm computes the layer's weight gradient in the launch of its input gradient."""
+    return K == 64 and N == 32 and M >= 8192
+
+
 def _gemm_kernel(a):
     """Which kernel stes_gemm dispatches to (the rules in stes_gemm_stream.hip and stes_gemm.hip)."""
     nb = _stream_slice(a.N)
@@ -237,7 +244,8 @@ def _gemm_kernel(a):
                  and not a.relu_mask and not a.bias and a.act == 0 and a.out_scale in (0.0, 1.0)
                  and (not a.a_scale or 8 * a.K <= 16 * (nb * 2 + 16)) and (not a.a_gate or (a.a_scale and a.gate_group >= 32)))
     if stream_ok:
-        return "gemm_stream_kernel<%d, %d, %d, %d, %d, %d>" % ((nb // 16, 8 if nb >= 128 else 4, pro) + _RING[a.K])
+        return ("gemm_stream_wg_kernel" if a.wg_dw else "gemm_stream_kernel") + "<%d, %d, %d, %d, %d, %d>" % (
+            (nb // 16, 8 if nb >= 128 else 4, pro) + _RING[a.K])
     if (not a.a_scale and not a.a_gate and a.k0 == 0 and a.map_stride <= 1 and not a.col_sum and a.n_split == 0
             and a.M * a.N * a.K <= (1 << 28) and a.M <= 16 * 65535):
         return "gemm_small_kernel"
@@ -249,8 +257,9 @@ def _gemm_kernel(a):
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
          bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0,
-         bn_bwd=None):
-    """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta), a_out | None)."""
+         bn_bwd=None, wgrad_fused=None):
+    """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta), a_out | None);
+    wgrad_fused = (Q, dW, Q0 | None, ldq0, k0, perm_fold): the layer's weight gradient in the same launch (gemm_fuses_wgrad)."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
     a.A0, a.lda0, a.k0 = ptr(A0), lda0, k0
@@ -270,8 +279,14 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
         raw, coef, a_out = bn_bwd
         a.a_raw, a.bn_alpha, a.bn_beta, a.bn_delta = ptr(raw), ptr(coef[0]), ptr(coef[1]), ptr(coef[2])
         a.a_out, a.lda_out = ptr(a_out), K
+    if wgrad_fused is not None:
+        q, dw, q0, ldq0, wk0, perm = wgrad_fused
+        a.wg_q, a.wg_ldq, a.wg_q0, a.wg_ldq0, a.wg_k0, a.wg_perm_fold = ptr(q), N, ptr(q0), ldq0, wk0, perm
+        a.wg_dw, a.wg_lddw = ptr(dw), N
     if TIMING is not None:
         byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
+        if a.wg_dw:
+            byt, fl = byt + 2 * a.M * a.N, 2 * fl
         _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))
         return
     check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")

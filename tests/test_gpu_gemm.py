@@ -256,6 +256,49 @@ def test_gemm_bn_backward_prologue_equals_apply_then_gemm(N, K):
         lib.gemm(dD, dW_, C2, 4096, N, K, bn_bwd=(dR, coef, None))          # too few rows for the streaming kernel
 
 
+@pytest.mark.parametrize("M,k0", [(3 * 53 * 52, 8), (8192 + 19, 0), (16 * 1024, 16)])
+def test_gemm_with_fused_weight_gradient_equals_gemm_then_wgrad(M, k0):
+    """K = 64, N = 32 (stage 1's first 1x1 conv): the input-gradient GEMM with the BatchNorm-backward prologue also produces the
+    layer's weight gradient.  Against the two-launch form (prologue GEMM writing the operand, stes_wgrad reading it): the GEMM
+    output bit for bit, the weight gradient to fp32 summation order -- with the gated-shift operand split and column
+    permutation, and a row count that is not a multiple of the 32-row tile."""
+    from spot_amd import lib
+    N, K = 32, 64
+    g = torch.Generator().manual_seed(M + k0)
+    D, raw, W, Q = _bf(M, K, g=g), _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5), _bf(M, N, g=g)
+    Q0 = _bf(M, max(k0, 8), g=g)
+    coef = [dev(torch.randn(K, generator=g) * s) for s in (1.0, 0.3, 0.1)]
+    dD, dR, dW_, dQ, dQ0 = dev(D), dev(raw), dev(W), dev(Q), dev(Q0)
+    assert lib.gemm_fuses_wgrad(M, N, K)
+    C_ref = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    dc = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(dD, dW_, C_ref, M, N, K, bn_bwd=(dR, coef, dc))
+    gw_ref = torch.ones(K, N, device="cuda")
+    lib.wgrad(dc, dQ, gw_ref, M, K, N, Q0=dQ0 if k0 else None, ldq0=Q0.shape[1], k0=k0, perm_fold=k0)
+    C_got = torch.full((M, N), 9.0, dtype=torch.bfloat16, device="cuda")
+    gw_got = torch.ones(K, N, device="cuda")
+    lib.gemm(dD, dW_, C_got, M, N, K, bn_bwd=(dR, coef, None), wgrad_fused=(dQ, gw_got, dQ0 if k0 else None, Q0.shape[1], k0, k0))
+    torch.cuda.synchronize()
+    assert torch.equal(C_got.view(torch.int16), C_ref.view(torch.int16))
+    torch.testing.assert_close(gw_got, gw_ref, rtol=1e-4, atol=1e-3 * M ** 0.5 * 1e-1)
+    # and against the definition
+    qeff = Q.float().clone()
+    if k0:
+        qeff[:, :k0] = Q0.float()[:, :k0]
+    want = dc.float().cpu().t() @ qeff
+    if k0:
+        half, quarter = k0 // 2, k0 // 4
+        dest = [(c // half) * half + 2 * ((c % half) % quarter) + (c % half) // quarter for c in range(k0)]
+        perm = want.clone()
+        perm[:, dest] = want[:, :k0]
+        want = perm
+    torch.testing.assert_close(gw_got.cpu() - 1.0, want, rtol=2e-3, atol=2e-3 * M ** 0.5)
+    with pytest.raises(lib.StesError):            # another shape: refused, not silently dropped
+        lib.gemm(dev(_bf(M, 128, g=g)), dev(_bf(64, 128, g=g)), torch.empty(M, 64, dtype=torch.bfloat16, device="cuda"), M, 64, 128,
+                 bn_bwd=(dev(_bf(M, 128, g=g)), [dev(torch.randn(128)) for _ in range(3)], None),
+                 wgrad_fused=(dev(_bf(M, 64, g=g)), torch.zeros(128, 64, device="cuda"), None, 0, 0, 0))
+
+
 @pytest.mark.parametrize("N1,N2", [(32, 32), (64, 24), (32, 128)])
 def test_wgrad_bn_backward_prologue_equals_apply_then_wgrad(N1, N2):
     """stes_wgrad with the BatchNorm-backward prologue on P (the stem's path: no input gradient, so no GEMM to do it)

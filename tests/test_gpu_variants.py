@@ -261,9 +261,9 @@ def test_sliding_window_events_match_oracle():
     # oracle through the same harness arithmetic
     wins = []
     for s in range(0, 44, 8):
-        clip = frames[s:s + 8]
-        if clip.shape[0] < 8:
-            clip = torch.cat([clip, torch.zeros(8 - clip.shape[0], 3, 64, 64)], 0)
+        # the last window is filled up with black frames: (0 - mean) / std in an already normalised clip, because the reference
+        # pads before its Normalize transform (inference_on_mp4.py:523-524)
+        clip = infer.pad_last_window(frames[s:s + 8], 8)
         _, sc, lc = O.predict(om, clip)
         wins.append((s, sc[0], lc[0]))
     osc, oloc = O.accumulate_windows(44, 7, wins)
@@ -280,7 +280,7 @@ def test_sliding_window_events_match_oracle():
     for r in range(2):
         acc = infer.ScoreAccumulator(44, 7)
         for starts in infer.window_batches(44, 8, 2, r, 2):
-            batch = torch.stack([torch.cat([frames[s:s + 8], torch.zeros(max(0, s + 8 - 44), 3, 64, 64)], 0) for s in starts])
+            batch = torch.stack([infer.pad_last_window(frames[s:s + 8], 8) for s in starts])
             _, sc, lc = m.predict(batch)
             for i, s in enumerate(starts):
                 acc.add(s, sc[i], lc[i])
