@@ -215,6 +215,26 @@ int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, i
 int stes_im2col_stem_u8(const uint8_t* x, uint16_t* patches, const float* mean, const float* std, int B, int T, int T_valid,
                         int Cin, int H, int W, void* stream);
 
+/* ---------------------------------------------------- clip augmentation ----
+ * The training loader's random augmentation (reference dataset/frame.py:78-140, applied per clip with one set of random
+ * parameters, :296-323) on decoded uint8 frames x [n_clips*T][3][Hs][Ws]: ONE resampling through a per-clip homography (the
+ * composition of the loader's crop / resized crop / flip / zoom-out / perspective / rotation / affine / Resize choices; zeros
+ * outside the source like torchvision's fill=0), then, each only when its flag is set, hue shift, saturation, brightness,
+ * contrast (against the frame's mean grey value), 5x5 Gaussian blur with reflected borders, and Normalize.
+ * params [n_clips][STES_AUGMENT_PARAMS] f32 (device):
+ *   [0..8]  row-major 3x3 map from output coordinates (pixel index + 0.5) to source coordinates (pixel index + 0.5)
+ *   [9]     != 0: nearest-neighbour instead of bilinear
+ *   [10,11] hue flag, shift (fraction of the colour circle)        [12,13] saturation flag, factor
+ *   [14,15] brightness flag, factor                                [16,17] contrast flag, factor
+ *   [18]    blur flag, [19..23] the five normalised Gaussian taps  [24..26] mean, [27..29] std of Normalize
+ * Output: exactly one of out_f32 [n][3][Ho][Wo] = (v - mean)/std (what the loader hands to the model; feeds stes_im2col_stem)
+ * or out_u8 = round(255 v) (feeds stes_im2col_stem_u8).  ws: stes_augment_ws_floats(n_clips*T, Ho, Wo) floats of workspace.
+ * Results do not depend on scheduling (the frame mean is added up in a fixed order).                                        */
+#define STES_AUGMENT_PARAMS 32
+int64_t stes_augment_ws_floats(int n_frames, int Ho, int Wo);
+int stes_augment_u8(const uint8_t* x, float* out_f32, uint8_t* out_u8, const float* params, float* ws, int64_t ws_floats,
+                    int n_clips, int T, int Hs, int Ws, int Ho, int Wo, void* stream);
+
 /* ---------------------------------------------------- temporal shift ----
  * Gated Shift Module, reference model/shift.py:83-161 (_GSM.forward :103-130, GatedShift.forward :157-161).
  * Xc is the COMPACT copy [B*T*H*W][fold] (NHWC bf16) of the first `fold` channels of the block input.  All tensors keep

@@ -92,6 +92,7 @@ _SIGS = {
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem_u8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_augment_u8": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gsm_prep": [_P, _P, _I32, _P],
     "stes_gsm_gate": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stes_gsm_shift": [_P, _P, _P, _P, _P],
@@ -114,7 +115,8 @@ _SIGS = {
     "stes_cast_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
-EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats", "stes_wgrad_ws_floats"] + list(_SIGS)
+EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats", "stes_wgrad_ws_floats",
+           "stes_augment_ws_floats"] + list(_SIGS)
 
 
 def lib():
@@ -132,6 +134,8 @@ def lib():
         L.stes_gru_ws_floats.restype = C.c_int64
         L.stes_wgrad_ws_floats.argtypes = []
         L.stes_wgrad_ws_floats.restype = C.c_int64
+        L.stes_augment_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.stes_augment_ws_floats.restype = C.c_int64
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig

@@ -2,8 +2,8 @@
 the parts that touch the model -- optimizer, warm-up + cosine schedule, epochs, checkpoints, resume -- with the reference's
 flag names, file names and file contents, so a `save_dir` written here is read by the reference and the other way round.
 
-What is NOT here is the reference's frame reader and augmentation stack (dataset/frame.py): at >10^4 frames/s a GPU is fed
-from pre-decoded clips.  `frame_dir` holds shards `train_*.npz` / `val_*.npz` with
+What is NOT here is the reference's JPEG frame reader (dataset/frame.py:20-65): at >10^4 frames/s a GPU is fed from
+pre-decoded clips; its random augmentation (dataset/frame.py:78-140) runs on the GPU under `--augment` (spot_amd/augment.py).  `frame_dir` holds shards `train_*.npz` / `val_*.npz` with
 
     frame uint8 [n, clip_len, 3, H, W]   decoded RGB frames (the stem normalises them on the GPU)
     label int64 [n, clip_len]            0 = background
@@ -65,6 +65,9 @@ def get_args(argv=None):
     p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--fused", action="store_true", help="HIP loss + backward + AdamW (implied under torchrun)")
+    p.add_argument("--augment", action="store_true",
+                   help="the reference loader's random augmentation (dataset/frame.py:78-140) on the GPU; shards may then hold "
+                        "frames of any size (validation clips are resized to crop_dim)")
     return p.parse_args(argv)
 
 
@@ -117,7 +120,34 @@ class SyntheticClips:
                    "xy": torch.rand(self.bs, self.T, 2, generator=g)}
 
 
+class AugmentedClips:
+    """A loader's batches through the reference's transform stack (dataset/frame.py:78-140: random geometry and colour for
+    training clips, Resize + Normalize for evaluation clips), whole batches at a time on the GPU: uint8 frames go up, the
+    normalised fp32 tensor the reference's loader would have produced comes back, `xy` moves with the pixels."""
+
+    def __init__(self, loader, device, crop_dim, is_eval, seed):
+        from .augment import ClipAugmenter
+        self.loader, self.device = loader, device
+        self.aug = ClipAugmenter(crop_dim, is_eval=is_eval, seed=seed)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            frame, xy = self.aug(batch["frame"].to(self.device, non_blocking=True), batch["xy"])
+            yield {**batch, "frame": frame, "xy": xy}
+
+
 def get_loaders(args, num_classes, rank=0, world=1):
+    tr, va = _get_loaders(args, num_classes, rank, world)
+    if getattr(args, "augment", False):
+        tr = AugmentedClips(tr, args.device, args.crop_dim, False, 1000 + rank)
+        va = AugmentedClips(va, args.device, args.crop_dim, True, 0)
+    return tr, va
+
+
+def _get_loaders(args, num_classes, rank=0, world=1):
     bs = args.batch_size // args.acc_grad_iter
     if args.frame_dir.startswith("synthetic"):
         n = int(args.frame_dir.split(":")[1]) if ":" in args.frame_dir else 4 * args.batch_size
