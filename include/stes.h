@@ -63,10 +63,13 @@ typedef struct {
     /* Weight gradient of the same layer in the same launch (optional, with the BatchNorm-backward prologue only):
      * wg_dw[K, N] (f32, leading dimension wg_lddw, atomics; caller zeroes) += pro(A)[M,K]^T * Q[M,N], Q's columns [0,wg_k0) taken
      * from the compact tensor wg_q0 (as stes_wgrad's Q0/k0) and the columns [0,wg_perm_fold) of wg_dw permuted like
-     * stes_wgrad's perm_fold.  pro(A) then never travels through memory: no a_out, no stes_wgrad launch.  Built for K = 64,
-     * N = 32 (stage 1's first 1x1 conv, 12.8 M rows at the named configuration); other shapes: STES_ERR_UNSUPPORTED.        */
+     * stes_wgrad's perm_fold.  pro(A) then never travels through memory: no a_out, no stes_wgrad launch.  With
+     * wg_map_stride > 1 row m of Q is the input pixel (n, ho*s, wo*s) of an Hi x Wi image (the Ho/Wo/Hi/Wi fields above; the
+     * weight gradient of a strided 1x1 shortcut conv, whose input gradient is computed at the output resolution).  Built for
+     * K = 64, N = 32 (stage 1's first 1x1 conv, 12.8 M rows at the named configuration, and its shortcut conv); other shapes:
+     * STES_ERR_UNSUPPORTED.                                                                                                 */
     const uint16_t* wg_q; int64_t wg_ldq; const uint16_t* wg_q0; int64_t wg_ldq0; int32_t wg_k0; int32_t wg_perm_fold;
-    float* wg_dw; int64_t wg_lddw;
+    float* wg_dw; int64_t wg_lddw; int32_t wg_map_stride;
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 

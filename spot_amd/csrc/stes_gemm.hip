@@ -789,6 +789,8 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     // tall-and-skinny bf16 layers with small K and N: weights resident in LDS, rows streamed (stes_gemm_stream.hip)
     STES_CHECK(!a->wg_dw || (bnb && a->wg_q && !a->a_out && a->wg_ldq >= a->N && a->wg_lddw >= a->N && a->wg_k0 % 8 == 0 && (a->wg_k0 == 0 || a->wg_q0)),
                STES_ERR_ARG, "stes_gemm: the fused weight gradient needs the BatchNorm-backward prologue, Q and no a_out");
+    STES_CHECK(!a->wg_dw || a->wg_map_stride <= 1 || (a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0 && a->M % ((long)a->Ho * a->Wo) == 0),
+               STES_ERR_ARG, "stes_gemm: row map dims of the fused weight gradient's Q");
     if (stes_gemm_stream(a, stream)) {
         STES_LAUNCH_CHECK();
         return STES_OK;

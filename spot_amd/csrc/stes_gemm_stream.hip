@@ -144,6 +144,12 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
                 const int id = lane + 64 * c, row = id / (NB / 8), cc = id % (NB / 8);
                 long m = tile * TR + row;
                 if (m >= M) m = M - 1;
+                if (p.wg_map_stride > 1) {
+                    uint32_t n, rem, ho, wo;
+                    fdivmod((uint32_t)m, dv.hw, n, rem);
+                    fdivmod(rem, dv.wo, ho, wo);
+                    m = ((long)n * p.Hi + (long)ho * p.wg_map_stride) * p.Wi + (long)wo * p.wg_map_stride;
+                }
                 fq_src[c] = (cc * 8 < p.wg_k0) ? (const bf16*)p.wg_q0 + m * p.wg_ldq0 + cc * 8 : (const bf16*)p.wg_q + m * p.wg_ldq + cc * 8;
             }
         }
@@ -463,6 +469,7 @@ static bool launch_k(const stes_gemm_args* a, hipStream_t stream, const StreamDi
             if (a->wg_dw) return false;
             // (with the gate prologue the two gate rows must fit the wave's staging buffer: slices of 128 columns and more)
             if constexpr (PRO == 0) { launch<NI, WAVES, PRO, 10, 2, 1>(a, stream, dv); return true; } else if constexpr (PRO != 1 || NI >= 8) { launch<NI, WAVES, PRO, 10, 1, 1>(a, stream, dv); return true; } else return false;
+        // (the fused weight gradient at K = 128, N = 64 needs 128 more accumulator registers than two waves per SIMD have: 319 spills)
         case 128: if (a->wg_dw) return false; launch<NI, WAVES, PRO, 4, 1, 2>(a, stream, dv); return true;
         case 64:
             if constexpr (PRO == 2 && NI == 2) { if (a->wg_dw) { launch<NI, WAVES, PRO, 2, 2, 2, true>(a, stream, dv); return true; } }
@@ -496,8 +503,9 @@ int stes_gemm_stream(const stes_gemm_args* a, void* stream) {
     const int nb = stes_stream_slice(a);
     if (nb == 0) return 0;
     StreamDivs dv;
-    dv.hw = make_fastdiv(a->map_stride > 1 ? a->Ho * a->Wo : 1);
-    dv.wo = make_fastdiv(a->map_stride > 1 ? a->Wo : 1);
+    const bool mapped = a->map_stride > 1 || (a->wg_dw && a->wg_map_stride > 1);
+    dv.hw = make_fastdiv(mapped ? a->Ho * a->Wo : 1);
+    dv.wo = make_fastdiv(mapped ? a->Wo : 1);
     dv.gate = make_fastdiv(a->a_gate ? a->gate_group : 1);
     const int pro = a->a_raw ? 2 : (a->a_scale ? 1 : 0);
     hipStream_t s = (hipStream_t)stream;

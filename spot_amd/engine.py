@@ -311,13 +311,17 @@ class Block:
             bnd = self.bnd
             bnd.bwd_finalize(Mo, s_dy=bn3.s_dy)
             dsc, Dsc = sc("dsc", Mo * cout), sc("Dsc", Mo * cin)
-            if lib.gemm_streams(Mo, cin, cout):
-                lib.gemm(dZ, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np, bn_bwd=(self.sc, bnd.coef, dsc))
-            else:
-                lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
-                lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
             rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
-            side(lambda: lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap))
+            if lib.gemm_streams(Mo, cin, cout) and lib.gemm_fuses_wgrad(Mo, cin, cout):
+                lib.gemm(dZ, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np, bn_bwd=(self.sc, bnd.coef, None),
+                         wgrad_fused=(a_src, g(self.ld.w), None, 0, 0, 0, rowmap))
+            else:
+                if lib.gemm_streams(Mo, cin, cout):
+                    lib.gemm(dZ, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np, bn_bwd=(self.sc, bnd.coef, dsc))
+                else:
+                    lib.bn_bwd_apply(dZ, self.sc, Mo, cout, bnd.coef, dsc)
+                    lib.gemm(dsc, self.ld.wT_bf, Dsc, Mo, cin, cout, ldw=self.ld.Np)
+                side(lambda: lib.wgrad(dsc, a_src, g(self.ld.w), Mo, cout, cin, rowmap=rowmap))
             resid, ms = Dsc, self.stride
         else:
             resid, ms = dZ, 1

@@ -40,7 +40,7 @@ GemmArgs = _struct("GemmArgs", [
     ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32),
     ("a_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("a_out", _P), ("lda_out", _I64),
     ("wg_q", _P), ("wg_ldq", _I64), ("wg_q0", _P), ("wg_ldq0", _I64), ("wg_k0", _I32), ("wg_perm_fold", _I32),
-    ("wg_dw", _P), ("wg_lddw", _I64)])
+    ("wg_dw", _P), ("wg_lddw", _I64), ("wg_map_stride", _I32)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -237,7 +237,7 @@ _RING = {320: (10, 1, 1), 128: (4, 1, 2), 64: (2, 2, 2), 32: (1, 4, 2)}       # 
 
 def gemm_fuses_wgrad(M, N, K):
     """Shapes for which stes_gemm computes the layer's weight gradient in the launch of its input gradient."""
-    return K == 64 and N == 32 and M >= 8192
+    return (K, N) == (64, 32) and M >= 8192
 
 
 def _gemm_kernel(a):
@@ -263,7 +263,8 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
          bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0,
          bn_bwd=None, wgrad_fused=None):
     """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta), a_out | None);
-    wgrad_fused = (Q, dW, Q0 | None, ldq0, k0, perm_fold): the layer's weight gradient in the same launch (gemm_fuses_wgrad)."""
+    wgrad_fused = (Q, dW, Q0 | None, ldq0, k0, perm_fold[, rowmap]): the layer's weight gradient in the same launch
+    (gemm_fuses_wgrad); rowmap = (stride, Ho, Wo, Hi, Wi) reads Q's rows through a strided 1x1 conv's pixel map."""
     a = GemmArgs()
     a.A, a.lda = ptr(A), lda if lda is not None else K
     a.A0, a.lda0, a.k0 = ptr(A0), lda0, k0
@@ -284,9 +285,11 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
         a.a_raw, a.bn_alpha, a.bn_beta, a.bn_delta = ptr(raw), ptr(coef[0]), ptr(coef[1]), ptr(coef[2])
         a.a_out, a.lda_out = ptr(a_out), K
     if wgrad_fused is not None:
-        q, dw, q0, ldq0, wk0, perm = wgrad_fused
+        q, dw, q0, ldq0, wk0, perm = wgrad_fused[:6]
         a.wg_q, a.wg_ldq, a.wg_q0, a.wg_ldq0, a.wg_k0, a.wg_perm_fold = ptr(q), N, ptr(q0), ldq0, wk0, perm
         a.wg_dw, a.wg_lddw = ptr(dw), N
+        if len(wgrad_fused) > 6 and wgrad_fused[6] is not None:
+            a.wg_map_stride, a.Ho, a.Wo, a.Hi, a.Wi = wgrad_fused[6]
     if TIMING is not None:
         byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
         if a.wg_dw:

@@ -299,6 +299,33 @@ def test_gemm_with_fused_weight_gradient_equals_gemm_then_wgrad(M, k0):
                  wgrad_fused=(dev(_bf(M, 64, g=g)), torch.zeros(128, 64, device="cuda"), None, 0, 0, 0))
 
 
+@pytest.mark.parametrize("n,Ho,Wo", [(5, 41, 43), (3, 56, 56)])
+def test_gemm_with_fused_weight_gradient_of_a_strided_shortcut(n, Ho, Wo):
+    """The same for a stride-2 1x1 shortcut conv: the input gradient lives at the output resolution (M = n*Ho*Wo rows) and the
+    weight gradient's Q rows are the input pixels (n, 2ho, 2wo) of the [n, Hi, Wi] block input."""
+    from spot_amd import lib
+    N, K, Hi, Wi = 32, 64, 2 * Ho + 1, 2 * Wo
+    M = n * Ho * Wo
+    g = torch.Generator().manual_seed(M)
+    D, raw, W, Q = _bf(M, K, g=g), _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5), _bf(n * Hi * Wi, N, g=g)
+    coef = [dev(torch.randn(K, generator=g) * s) for s in (1.0, 0.3, 0.1)]
+    dD, dR, dW_, dQ = dev(D), dev(raw), dev(W), dev(Q)
+    rowmap = (2, Ho, Wo, Hi, Wi)
+    C_ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    dc = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(dD, dW_, C_ref, M, N, K, bn_bwd=(dR, coef, dc))
+    gw_ref = torch.zeros(K, N, device="cuda")
+    lib.wgrad(dc, dQ, gw_ref, M, K, N, rowmap=rowmap)
+    C_got = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    gw_got = torch.zeros(K, N, device="cuda")
+    lib.gemm(dD, dW_, C_got, M, N, K, bn_bwd=(dR, coef, None), wgrad_fused=(dQ, gw_got, None, 0, 0, 0, rowmap))
+    torch.cuda.synchronize()
+    assert torch.equal(C_got.view(torch.int16), C_ref.view(torch.int16))
+    torch.testing.assert_close(gw_got, gw_ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
+    qs = Q.float().view(n, Hi, Wi, N)[:, 0:2 * Ho:2, 0:2 * Wo:2].reshape(M, N)
+    torch.testing.assert_close(gw_got.cpu(), dc.float().cpu().t() @ qs, rtol=2e-3, atol=2e-3 * M ** 0.5)
+
+
 @pytest.mark.parametrize("N1,N2", [(32, 32), (64, 24), (32, 128)])
 def test_wgrad_bn_backward_prologue_equals_apply_then_wgrad(N1, N2):
     """stes_wgrad with the BatchNorm-backward prologue on P (the stem's path: no input gradient, so no GEMM to do it)
