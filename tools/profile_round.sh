@@ -13,5 +13,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --serial > $out/pmc_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --serial > $out/pmc_write.log 2>&1
 # the trace files are large and not needed back (only the stats and the counter tables)
-rm -f $out/prof/*_kernel_trace.csv
+rm -f $out/prof/*_kernel_trace.csv $out/prof_serial/*_kernel_trace.csv
+# the bench lines read the dominant kernel's HBM traffic from profiles/pmc_traffic.json: rebuild it from the passes above first
+python3 tools/pmc_traffic.py $out/pmc_fetch/${tag}_counter_collection.csv $out/pmc_write/${tag}_counter_collection.csv > profiles/pmc_traffic.json
+timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err
+for cfg in train_tsm_mingru infer_fwd infer_long_video; do
+    timeout -k 10 300 python3 bench.py --config $cfg --no-cpu-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err
+done
+timeout -k 10 120 python3 tools/bench_augment.py > $out/augment.txt 2>&1
 echo profiles done
