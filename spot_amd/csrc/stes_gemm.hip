@@ -36,7 +36,7 @@ struct RowInfo {
 struct RowDivs { FastDiv hw, wo, gate; };
 
 template <int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv) {
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv) {
     constexpr int NI = BN / 32;          // 16-wide n fragments per wave (wave covers BN/2 columns)
     constexpr int BLOADS = BN / 64;      // W-tile chunk loads per thread
     // two k-steps of 32 per barrier (KB = 2 tiles per buffer): the barrier and the LDS round trip are paid once per 32 MFMAs
@@ -75,6 +75,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         for (int r = 0; r < 4; ++r) { csum[i][r] = 0.f; csq[i][r] = 0.f; }
     const bool stats = p.col_sum != nullptr;
     const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
+    // Row-store epilogue (full bf16 column tiles): a wave's 64 x BN/2 result goes through its own slice of the A buffer and
+    // leaves as 16-byte pieces that make up whole row segments.  Stored straight from the accumulator layout a store
+    // instruction covers 16 rows x 32 bytes, and those partial lines cost as much time as the k loop at K = 768.
+    constexpr int WN = BN / 2, CPR = WN / 8;            // columns per wave, 16-byte pieces per row
+    const bool row_store = !p.c_f32 && !p.relu_mask && (p.ldc & 7) == 0 && n0 + BN <= N &&
+                           (p.n_split == 0 || ((p.n_split & 7) == 0 && (p.ldc0 & 7) == 0));
+    // (its column sums live in csum[0..1][] / csq[0..1][]: a lane always reads back the same 8 columns)
 
     for (int mt = slot; mt < m_tiles; mt += m_slots) {
         const long m0 = (long)mt * BM;
@@ -199,6 +206,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         }
 
         // epilogue: lane holds, per (i, j), columns n = n0 + wn*BN/2 + i*16 + fq*4 + r of row m = m0 + wm*64 + j*16 + fr
+        if (row_store) {
+            // (the k loop ended on a barrier: nobody reads the operand buffers any more)
+            unsigned char* stg = reinterpret_cast<unsigned char*>(&As[0][0]) + wave * (64 * WN * 2);
+            auto piece = [](int row, int c) { return c ^ (CPR == 8 ? (row & 7) : ((row >> 1) & 3)); };   // bank spread
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int nb = n0 + wn * WN + i * 16 + fq * 4;
+                float bias[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bias[r] = p.bias[nb + r];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r] * out_scale + bias[r];
+                        if (p.act == 1) v = fmaxf(v, 0.f);
+                        else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
+                        o[r] = (bf16)v;
+                    }
+                    const int row = j * 16 + fr;
+                    *reinterpret_cast<bf16x4*>(stg + row * (WN * 2) + piece(row, i * 2 + (fq >> 1)) * 16 + (fq & 1) * 8) = o;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int c = lane % CPR, rsub = lane / CPR;
+            const int col = n0 + wn * WN + c * 8;
+            const bool to_c0 = col < p.n_split;
+            bf16* const o_base = to_c0 ? (bf16*)p.C0 + col : (bf16*)p.C + col;
+            const long o_ld = to_c0 ? p.ldc0 : p.ldc;
+#pragma unroll
+            for (int ps = 0; ps < 64 / (64 / CPR); ++ps) {
+                const int row = ps * (64 / CPR) + rsub;
+                const long m = m0 + wm * 64 + row;
+                if (m < M) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * (WN * 2) + piece(row, c) * 16);
+                    *reinterpret_cast<bf16x8*>(o_base + m * o_ld) = v;
+                    if (stats) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; csum[e >> 2][e & 3] += f; csq[e >> 2][e & 3] += f * f; }
+                    }
+                }
+            }
+            __syncthreads();                  // the next tile's operands go into the same buffer
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int nb = n0 + wn * (BN / 2) + i * 16 + fq * 4;
@@ -255,6 +311,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const stes_gemm_args p, int m
         // per-wave column sums -> LDS (the A tile is free: the k loop ended on a barrier) -> one contiguous atomic per column
         // per workgroup; scattered few-lane atomics on a handful of cache lines serialise in L2
         float* red = reinterpret_cast<float*>(&As[0][0]);      // [2 (wm)][2 (sum, sumsq)][BN]
+        if (row_store) {
+            // lanes with the same lane % CPR hold the same 8 columns
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sv = csum[e >> 2][e & 3], q = csq[e >> 2][e & 3];
+#pragma unroll
+                for (int o = CPR; o < 64; o <<= 1) { sv += __shfl_xor(sv, o, 64); q += __shfl_xor(q, o, 64); }
+                const int nl = wn * WN + (lane % CPR) * 8 + e;
+                if (lane < CPR) { red[(wm * 2 + 0) * BN + nl] = sv; red[(wm * 2 + 1) * BN + nl] = q; }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
