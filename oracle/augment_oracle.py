@@ -25,7 +25,7 @@ F = np.float32
 def _fetch(plane, x, y):
     H, W = plane.shape
     ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
-    v = plane[np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)].astype(F) / F(255.0)
+    v = plane[np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)].astype(F)      # the byte; /255 follows the interpolation
     return np.where(ok, v, F(0.0)).astype(F)
 
 
@@ -46,7 +46,7 @@ def warp(frame_u8, hinv, Ho, Wo, nearest=False):
     if nearest:
         xi, yi = np.rint(sx).astype(np.int64), np.rint(sy).astype(np.int64)
         for c in range(3):
-            out[c] = _fetch(frame_u8[c], xi, yi)
+            out[c] = _fetch(frame_u8[c], xi, yi) / F(255.0)
     else:
         x0f, y0f = np.floor(sx), np.floor(sy)
         x0, y0 = x0f.astype(np.int64), y0f.astype(np.int64)
@@ -55,7 +55,7 @@ def warp(frame_u8, hinv, Ho, Wo, nearest=False):
         w00, w01, w10, w11 = (one - wx) * (one - wy), wx * (one - wy), (one - wx) * wy, wx * wy
         for c in range(3):
             p = frame_u8[c]
-            out[c] = ((_fetch(p, x0, y0) * w00 + _fetch(p, x0 + 1, y0) * w01) + _fetch(p, x0, y0 + 1) * w10) + _fetch(p, x0 + 1, y0 + 1) * w11
+            out[c] = (((_fetch(p, x0, y0) * w00 + _fetch(p, x0 + 1, y0) * w01) + _fetch(p, x0, y0 + 1) * w10) + _fetch(p, x0 + 1, y0 + 1) * w11) / F(255.0)
     return np.where(inside[None], out, F(0)).astype(F)
 
 

@@ -8,6 +8,7 @@
 //   1. augment_warp_kernel   gather + hue + saturation + brightness -> fp32 planes, per-workgroup partial sums of the grey value
 //   2. augment_finish_kernel frame mean (partials added in a fixed order: results do not depend on scheduling), contrast,
 //                            5x5 Gaussian blur with reflected borders, Normalize -> output
+// Clips with neither contrast nor blur (9 in 16 at the loader's p = 0.25) are finished by the first launch.
 // Threads run along x so that stores are whole rows; the gathers of neighbouring threads fall into neighbouring source bytes
 // for every map that is close to a similarity, and the source frame (267 KB at 398x224) stays in L2 while it is being read.
 #include "stes_common.h"
@@ -18,6 +19,7 @@
 namespace {
 
 constexpr int AUG_THREADS = 256;
+constexpr int AUG_VB = 8;          // 256-pixel pieces of a frame per workgroup (a workgroup per piece is bound by dispatch)
 constexpr int AUG_PARAMS = STES_AUGMENT_PARAMS;
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
@@ -25,8 +27,25 @@ __device__ __forceinline__ float grey_of(float r, float g, float b) { return 0.2
 // ratio*a + (1-ratio)*b clamped to [0,1]: the blend every ColorJitter step is made of
 __device__ __forceinline__ float blend(float a, float b, float ratio) { return clamp01(ratio * a + (1.f - ratio) * b); }
 
+// the byte as a float (0 outside the frame); the division by 255 follows the interpolation: one per channel instead of four
 __device__ __forceinline__ float fetch(const uint8_t* __restrict__ plane, int x, int y, int W, int H) {
-    return (x >= 0 && x < W && y >= 0 && y < H) ? (float)plane[(long)y * W + x] / 255.f : 0.f;
+    return (x >= 0 && x < W && y >= 0 && y < H) ? (float)plane[(long)y * W + x] : 0.f;
+}
+
+// The horizontal neighbours x0, x0 + 1 of row y in one two-byte load (any byte address): the gathers are bound by load
+// instructions per lane, not by bytes, and this halves them.  Pairs that straddle the frame's edge take single bytes.
+typedef uint16_t u16_any __attribute__((aligned(1)));
+__device__ __forceinline__ void fetch_pair(const uint8_t* __restrict__ plane, int x0, int y, int W, int H, float& a, float& b) {
+    a = 0.f; b = 0.f;
+    if (y < 0 || y >= H) return;
+    const uint8_t* row = plane + (long)y * W;
+    if (x0 >= 0 && x0 + 1 < W) {
+        const unsigned v = *reinterpret_cast<const u16_any*>(row + x0);
+        a = (float)(v & 0xffu); b = (float)(v >> 8);
+    } else {
+        if (x0 >= 0 && x0 < W) a = (float)row[x0];
+        if (x0 + 1 >= 0 && x0 + 1 < W) b = (float)row[x0 + 1];
+    }
 }
 
 // hue shift through HSV (the formulas of torchvision's _rgb_to_hsv / _hsv_to_rgb)
@@ -61,13 +80,17 @@ __device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float sh
     }
 }
 
+// A clip with neither contrast nor blur needs no second pass: its frames leave this kernel finished (out_f / out_u), and the
+// finish kernel skips them.
 __global__ __launch_bounds__(AUG_THREADS) void augment_warp_kernel(const uint8_t* __restrict__ x, float* __restrict__ tmp,
                                                                     float* __restrict__ partial, const float* __restrict__ params,
+                                                                    float* __restrict__ out_f, uint8_t* __restrict__ out_u,
                                                                     int T, int Hs, int Ws, int Ho, int Wo, int nblk) {
     __shared__ float red[AUG_THREADS / 64];
     const int frame = blockIdx.y;
     const float* __restrict__ P = params + (long)(frame / T) * AUG_PARAMS;
-    const int pix = blockIdx.x * AUG_THREADS + threadIdx.x;
+    for (int vb = blockIdx.x * AUG_VB; vb < (int)(blockIdx.x + 1) * AUG_VB && vb < nblk; ++vb) {
+    const int pix = vb * AUG_THREADS + threadIdx.x;
     const bool live = pix < Ho * Wo;
     float grey = 0.f;
     if (live) {
@@ -85,7 +108,7 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_warp_kernel(const uint8_t
         } else if (P[9] != 0.f) {               // nearest (ties to even, like grid_sample)
             const int xi = (int)rintf(sx), yi = (int)rintf(sy);
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) c[ch] = fetch(src + (long)ch * Hs * Ws, xi, yi, Ws, Hs);
+            for (int ch = 0; ch < 3; ++ch) c[ch] = fetch(src + (long)ch * Hs * Ws, xi, yi, Ws, Hs) / 255.f;
         } else {
             const float x0f = floorf(sx), y0f = floorf(sy);
             const int x0 = (int)x0f, y0 = (int)y0f;
@@ -94,8 +117,10 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_warp_kernel(const uint8_t
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 const uint8_t* pl = src + (long)ch * Hs * Ws;
-                c[ch] = ((fetch(pl, x0, y0, Ws, Hs) * w00 + fetch(pl, x0 + 1, y0, Ws, Hs) * w01) +
-                         fetch(pl, x0, y0 + 1, Ws, Hs) * w10) + fetch(pl, x0 + 1, y0 + 1, Ws, Hs) * w11;
+                float v00, v01, v10, v11;
+                fetch_pair(pl, x0, y0, Ws, Hs, v00, v01);
+                fetch_pair(pl, x0, y0 + 1, Ws, Hs, v10, v11);
+                c[ch] = (((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11) / 255.f;
             }
         }
         if (P[10] != 0.f) hue_shift(c[0], c[1], c[2], P[11]);
@@ -108,16 +133,27 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_warp_kernel(const uint8_t
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) c[ch] = blend(c[ch], 0.f, P[15]);
         }
-        float* __restrict__ dst = tmp + (long)frame * 3 * Ho * Wo + pix;
+        const long o = (long)frame * 3 * Ho * Wo + pix;
+        if (P[16] == 0.f && P[18] == 0.f) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) dst[(long)ch * Ho * Wo] = c[ch];
-        grey = grey_of(c[0], c[1], c[2]);
+            for (int ch = 0; ch < 3; ++ch) {
+                if (out_u) out_u[o + (long)ch * Ho * Wo] = (uint8_t)rintf(clamp01(c[ch]) * 255.f);
+                else out_f[o + (long)ch * Ho * Wo] = (c[ch] - P[24 + ch]) / P[27 + ch];
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) tmp[o + (long)ch * Ho * Wo] = c[ch];
+            grey = grey_of(c[0], c[1], c[2]);
+        }
     }
-    // fixed-order sum of the workgroup's grey values: lanes by xor butterfly, then the four waves in order
+    if (P[16] == 0.f) continue;                // (the whole workgroup: P belongs to the frame) no contrast, no frame mean
+    // fixed-order sum of the piece's grey values: lanes by xor butterfly, then the four waves in order
     grey = wave_sum(grey);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = grey;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(long)frame * nblk + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) partial[(long)frame * nblk + vb] = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    }
 }
 
 template <bool U8>
@@ -128,13 +164,15 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_finish_kernel(const float
     const int frame = blockIdx.y;
     const float* __restrict__ P = params + (long)(frame / T) * AUG_PARAMS;
     const bool contrast = P[16] != 0.f, blur = P[18] != 0.f;
+    if (!contrast && !blur) return;            // finished by the warp kernel
     if (contrast && threadIdx.x == 0) {
         float s = 0.f;
         for (int i = 0; i < nblk; ++i) s += partial[(long)frame * nblk + i];
         mean_s = s / (float)(Ho * Wo);
     }
     __syncthreads();
-    const int pix = blockIdx.x * AUG_THREADS + threadIdx.x;
+    for (int vb = blockIdx.x * AUG_VB; vb < (int)(blockIdx.x + 1) * AUG_VB && vb < nblk; ++vb) {
+    const int pix = vb * AUG_THREADS + threadIdx.x;
     if (pix >= Ho * Wo) return;
     const int oy = pix / Wo, ox = pix - oy * Wo;
     const float cf = P[17];
@@ -169,6 +207,7 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_finish_kernel(const float
             out_f[(long)frame * 3 * Ho * Wo + (long)ch * Ho * Wo + pix] = (v - P[24 + ch]) / P[27 + ch];
         }
     }
+    }
 }
 
 }  // namespace
@@ -190,9 +229,9 @@ extern "C" int stes_augment_u8(const uint8_t* x, float* out_f32, uint8_t* out_u8
     const int nblk = stes_div_up((long)Ho * Wo, AUG_THREADS);
     float* tmp = ws;
     float* partial = ws + n_frames * 3 * Ho * Wo;
-    const dim3 grid(nblk, (unsigned)n_frames);
+    const dim3 grid(stes_div_up(nblk, AUG_VB), (unsigned)n_frames);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(augment_warp_kernel, grid, dim3(AUG_THREADS), 0, s, x, tmp, partial, params, T, Hs, Ws, Ho, Wo, nblk);
+    hipLaunchKernelGGL(augment_warp_kernel, grid, dim3(AUG_THREADS), 0, s, x, tmp, partial, params, out_f32, out_u8, T, Hs, Ws, Ho, Wo, nblk);
     if (out_u8)
         hipLaunchKernelGGL(augment_finish_kernel<true>, grid, dim3(AUG_THREADS), 0, s, tmp, partial, params, out_f32, out_u8, T, Ho, Wo, nblk);
     else
