@@ -333,8 +333,9 @@ int stes_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int stes_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int ld, int dst_rows, int transpose, int perm_fold,
                    void* stream);
 /* The same for a whole table of copies in ONE launch.  `table` is DEVICE memory holding n entries; entry e owns the
- * workgroups [block0, block0 + ceil(dst_rows*ld / 256)) and the entries are sorted by block0 (entry 0 has block0 = 0);
- * total_blocks is the sum.  Field meaning as in stes_cast_bf16.                                                        */
+ * workgroups [block0, block0 + ceil(dst_rows*ld / STES_CAST_CHUNK)) and the entries are sorted by block0 (entry 0 has
+ * block0 = 0); total_blocks is the sum.  Field meaning as in stes_cast_bf16.                                            */
+#define STES_CAST_CHUNK 2048
 typedef struct {
     const float* src; uint16_t* dst;
     int32_t rows, cols, ld, dst_rows, transpose, perm_fold;

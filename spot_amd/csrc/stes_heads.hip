@@ -581,8 +581,9 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict
     }
 }
 
-// All weight copies of a step in one launch: workgroup -> (table entry, 256-element chunk) by binary search over the
-// entries' first workgroup.  ~140 launches of a few microseconds each otherwise sit at the head of every training step.
+// All weight copies of a step in one launch: workgroup -> (table entry, STES_CAST_CHUNK-element chunk) by binary search over
+// the entries' first workgroup.  ~140 launches of a few microseconds each otherwise sit at the head of every training step.
+// (A workgroup per 256 elements made 120,600 workgroups of the configuration's 16 M parameters: bound by dispatch, 133 us.)
 __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const stes_cast_desc* __restrict__ table, int n) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -590,16 +591,20 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const stes_cast_de
         if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const stes_cast_desc d = table[lo];
-    const long i = (long)(blockIdx.x - d.block0) * 256 + threadIdx.x;
-    if (i >= (long)d.dst_rows * d.ld) return;
-    const int dr = (int)(i / d.ld), dc = (int)(i - (long)dr * d.ld);
-    float v = 0.f;
-    if (!d.transpose) {
-        if (dr < d.rows && dc < d.cols) v = d.src[(long)dr * d.cols + (dc < d.perm_fold ? gsm_dest(dc, d.perm_fold) : dc)];
-    } else {
-        if (dc < d.rows && dr < d.cols) v = d.src[(long)dc * d.cols + (dr < d.perm_fold ? gsm_dest(dr, d.perm_fold) : dr)];
+    const long total = (long)d.dst_rows * d.ld;
+#pragma unroll
+    for (int j = 0; j < STES_CAST_CHUNK / 256; ++j) {
+        const long i = (long)(blockIdx.x - d.block0) * STES_CAST_CHUNK + j * 256 + threadIdx.x;
+        if (i >= total) return;
+        const int dr = (int)(i / d.ld), dc = (int)(i - (long)dr * d.ld);
+        float v = 0.f;
+        if (!d.transpose) {
+            if (dr < d.rows && dc < d.cols) v = d.src[(long)dr * d.cols + (dc < d.perm_fold ? gsm_dest(dc, d.perm_fold) : dc)];
+        } else {
+            if (dc < d.rows && dr < d.cols) v = d.src[(long)dc * d.cols + (dr < d.perm_fold ? gsm_dest(dr, d.perm_fold) : dr)];
+        }
+        reinterpret_cast<bf16*>(d.dst)[i] = (bf16)v;
     }
-    reinterpret_cast<bf16*>(d.dst)[i] = (bf16)v;
 }
 
 }  // namespace

@@ -599,7 +599,7 @@ class Engine:
             for d, (src, dst, rows, cols, ld, dst_rows, tr, pf) in zip(arr, self.casts):
                 d.src, d.dst, d.rows, d.cols, d.ld, d.dst_rows, d.transpose, d.perm_fold, d.block0 = (
                     src.data_ptr(), dst.data_ptr(), rows, cols, ld, dst_rows, tr, pf, blk)
-                blk += (dst_rows * ld + 255) // 256
+                blk += (dst_rows * ld + lib.CAST_CHUNK - 1) // lib.CAST_CHUNK
             self._cast_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             self._cast_blocks = blk
         lib.call("stes_cast_bf16_multi", p(self._cast_table), len(self.casts), self._cast_blocks)

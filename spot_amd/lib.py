@@ -61,6 +61,8 @@ BnBwdArgs = _struct("BnBwdArgs", [
 CastDesc = _struct("CastDesc", [("src", _P), ("dst", _P), ("rows", _I32), ("cols", _I32), ("ld", _I32), ("dst_rows", _I32),
                                 ("transpose", _I32), ("perm_fold", _I32), ("block0", _I32), ("reserved", _I32)])
 
+CAST_CHUNK = 2048        # STES_CAST_CHUNK in include/stes.h: destination elements per workgroup of stes_cast_bf16_multi
+
 GsmGeom = _struct("GsmGeom", [("B", _I32), ("T", _I32), ("H", _I32), ("W", _I32), ("fold", _I32)])
 
 GruArgs = _struct("GruArgs", [

@@ -787,7 +787,7 @@ def test_cast_bf16_multi_equals_single_launches():
     from spot_amd import lib
     g = torch.Generator().manual_seed(77)
     cases = [(40, 24, 24, 40, 0, 0), (40, 24, 40, 24, 1, 0), (33, 27, 32, 40, 0, 0), (64, 96, 96, 64, 0, 16), (64, 96, 64, 96, 1, 16),
-             (7, 768, 768, 8, 0, 0), (7, 768, 8, 768, 1, 0)]
+             (7, 768, 768, 8, 0, 0), (7, 768, 8, 768, 1, 0), (300, 24, 24, 300, 0, 0), (300, 24, 304, 24, 1, 0)]     # (the last two: several chunks)
     srcs = [dev(torch.randn(r, c, generator=g)) for r, c, *_ in cases]
     single = [torch.full((dr * ld,), 3.0, dtype=BF, device="cuda") for _, _, ld, dr, _, _ in cases]
     multi = [torch.full((dr * ld,), 4.0, dtype=BF, device="cuda") for _, _, ld, dr, _, _ in cases]
@@ -796,7 +796,7 @@ def test_cast_bf16_multi_equals_single_launches():
     for d, s, a, b, (r, c, ld, dr, tr, pf) in zip(arr, srcs, single, multi, cases):
         lib.call("stes_cast_bf16", lib.ptr(s), lib.ptr(a), r, c, ld, dr, tr, pf)
         d.src, d.dst, d.rows, d.cols, d.ld, d.dst_rows, d.transpose, d.perm_fold, d.block0 = s.data_ptr(), b.data_ptr(), r, c, ld, dr, tr, pf, blk
-        blk += (dr * ld + 255) // 256
+        blk += (dr * ld + lib.CAST_CHUNK - 1) // lib.CAST_CHUNK
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
     lib.call("stes_cast_bf16_multi", lib.ptr(table), len(cases), blk)
     torch.cuda.synchronize()
