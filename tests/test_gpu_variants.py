@@ -213,6 +213,41 @@ def test_short_clip_is_padded_then_unpadded_like_reference():
         m.predict(torch.zeros(1, 7, 3, 64, 64))
 
 
+def test_eval_forward_reuses_the_folded_batchnorm_until_something_changes():
+    """Evaluation folds the running statistics into scale/shift once: a second forward launches no BatchNorm finalize and
+    gives the same bits; an in-place change of a running statistic, a training step, or a loaded state dict is picked up."""
+    from spot_amd import lib
+    om, m = _pair("rny008_gsm", "gru", clip_len=4)
+    x = torch.randn(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(8))
+
+    def run():
+        lib.TIMING = []
+        try:
+            _, scores, _ = m.predict(x)
+            return scores, sum(t[0] == "bn_finalize_kernel" for t in lib.TIMING)
+        finally:
+            lib.TIMING = None
+    s1, n1 = run()
+    s2, n2 = run()
+    assert n1 > 50 and n2 == 0 and np.array_equal(s1, s2)
+    bn = m._model._features.stem.bn
+    bn.running_var.mul_(9.0)                               # from outside, in place
+    s3, n3 = run()
+    assert n3 == n1 and not np.array_equal(s3, s1)
+    bn.running_var.div_(9.0)
+    s4, n4 = run()
+    assert n4 == n1 and np.allclose(s4, s1, atol=1e-3)
+    # a training step moves weights and statistics
+    label = torch.zeros(2, 4, dtype=torch.long, device="cuda")
+    m.train_step(x.cuda(), label, torch.rand(2, 4, 2, device="cuda"), 1e-3)
+    s5, n5 = run()
+    assert n5 == n1 and not np.array_equal(s5, s1)
+    m._model.load_state_dict(om.state_dict(), strict=True)
+    s6, n6 = run()
+    assert n6 == n1 and np.array_equal(s6, s1)
+    assert run()[1] == 0
+
+
 def test_uint8_frames_equal_the_loaders_normalised_tensor():
     """Decoded uint8 clips at the boundary (`read_image`, reference dataset/frame.py:29) give the predictions of the fp32
     tensor the reference loader would have built from them (`/255`, Normalize :124), bit for bit in eval mode -- also for
