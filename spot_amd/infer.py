@@ -55,6 +55,7 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
     [{'video', 'events'}] list (after score filter 0.15 and NMS 3 when postprocess)."""
     n_frames = frames.shape[0]
     acc = ScoreAccumulator(n_frames, len(classes) + 1)
+    full_batch_seen = False
     for starts in window_batches(n_frames, clip_len, batch_size, rank, world):
         clips = []
         for s in starts:
@@ -64,6 +65,11 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
             if clip.shape[0] < clip_len:
                 clip = pad_last_window(clip, clip_len, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
             clips.append(clip)
+        if full_batch_seen and len(clips) < batch_size:
+            # a ragged last batch would make the engine lay out its activations for another batch size (and back again for
+            # the next video): the last window is repeated instead and the repeats' outputs are dropped
+            clips += [clips[-1]] * (batch_size - len(clips))
+        full_batch_seen = full_batch_seen or len(clips) == batch_size
         batch = torch.stack(clips, 0)
         out = model.predict(batch)
         scores, loc = out[1], (out[2] if len(out) > 2 else None)

@@ -33,12 +33,10 @@ class ScoreAccumulator:
 def events_from_scores(scores: np.ndarray, locations: np.ndarray, classes):
     """argmax != background -> event (inference_on_mp4.py:247-262)."""
     pred = np.argmax(scores, axis=1)
-    events = []
-    for i in range(pred.shape[0]):
-        if pred[i] != 0:
-            events.append({"label": classes[pred[i] - 1], "frame": i, "score": scores[i, pred[i]].item(),
-                           "xy": locations[i].tolist()})
-    return events
+    idx = np.nonzero(pred)[0]                       # only the foreground frames are visited (a few per cent of a video)
+    cls = pred[idx]
+    return [{"label": classes[c - 1], "frame": i, "score": s, "xy": xy}
+            for i, c, s, xy in zip(idx.tolist(), cls.tolist(), scores[idx, cls].tolist(), locations[idx].tolist())]
 
 
 def filter_events_by_score(data, fg_threshold):
