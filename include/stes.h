@@ -70,6 +70,14 @@ typedef struct {
      * STES_ERR_UNSUPPORTED.                                                                                                 */
     const uint16_t* wg_q; int64_t wg_ldq; const uint16_t* wg_q0; int64_t wg_ldq0; int32_t wg_k0; int32_t wg_perm_fold;
     float* wg_dw; int64_t wg_lddw; int32_t wg_map_stride;
+    /* Block-tail epilogue (optional; streaming shapes, bf16 output, no statistics, no split output): with e_scale / e_shift [N]
+     * the value stored at C[m,n] is relu(e_scale[n]*c + e_shift[n] + r) with c the bf16-rounded product and r = e_res[m,n]
+     * (bf16, leading dimension e_ldres), or e_rscale[n]*e_res[m,n] + e_rshift[n] when e_rscale is given; columns
+     * [0, e_slice_n) of the result are also copied to the compact tensor e_slice [M][e_slice_n].  This is
+     * stes_bn_act_residual applied to this product without the product's trip through memory, for evaluation, where the
+     * BatchNorm over the product is a fixed affine map (timm Bottleneck: conv3.bn + shortcut + act3).                       */
+    const float* e_scale; const float* e_shift; const uint16_t* e_res; int64_t e_ldres; const float* e_rscale; const float* e_rshift;
+    uint16_t* e_slice; int32_t e_slice_n;
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 

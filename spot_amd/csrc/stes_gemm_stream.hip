@@ -46,7 +46,9 @@ __device__ __forceinline__ int wg_dest(int c, int fold) {    // within-group cha
     return g * half + 2 * j + i;
 }
 
-template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG>   // NB = 16*NI columns per workgroup
+// TAIL: the block-tail epilogue relu(e_scale*c + e_shift + residual) on the staged rows (evaluation forward of a bottleneck's
+// last 1x1 conv); its own instantiations, because the residual rows it keeps in flight cost registers every other form needs.
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG, bool TAIL = false>   // NB = 16*NI columns per workgroup
 __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int row_tiles, int n_slices, int m_slots, const StreamDivs& dv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(!WG || (PRO == 2 && J == 2), "the fused weight gradient rides on the BatchNorm-backward form with 32-row tiles");
@@ -70,8 +72,9 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
     float* sh_s = sc_s + K;
     float* de_s = sh_s + K;                     // BNB: sc_s = alpha, sh_s = beta, de_s = delta
     float* red = de_s + K;                      // [2][NB]
+    float* epi_l = red + 2 * NB;                // [4][NB]: block-tail epilogue scale, shift, residual scale, residual shift
     constexpr int WG_PSUB = K / 16, WG_QSUB = NB / 16;                         // [32][16] bf16 sub-tiles (1 KiB each) of pro(A) and of Q
-    unsigned char* wgl = reinterpret_cast<unsigned char*>(red + 2 * NB) + wave * (WG_PSUB + WG_QSUB) * 1024;
+    unsigned char* wgl = reinterpret_cast<unsigned char*>(epi_l + 4 * NB) + wave * (WG_PSUB + WG_QSUB) * 1024;
     // AFF: this wave's copy of the gate rows of the (at most two) images its current tile touches, or ones without a gate.
     // It lives in the wave's output staging buffer: the gate is read in the k loop, the staging buffer in the tile epilogue.
     float* gl = reinterpret_cast<float*>(stage);
@@ -97,6 +100,10 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
         if (AFF) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.a_scale[k]; sh_s[k] = p.a_shift[k]; }
         if (BNB) for (int k = tid; k < K; k += WAVES * 64) { sc_s[k] = p.bn_alpha[k]; sh_s[k] = p.bn_beta[k]; de_s[k] = p.bn_delta[k]; }
         for (int k = tid; k < 2 * NB; k += WAVES * 64) red[k] = 0.f;
+        if constexpr (TAIL) for (int k = tid; k < NB; k += WAVES * 64) {
+            epi_l[k] = p.e_scale[n0 + k]; epi_l[NB + k] = p.e_shift[n0 + k];
+            epi_l[2 * NB + k] = p.e_rscale ? p.e_rscale[n0 + k] : 1.f; epi_l[3 * NB + k] = p.e_rscale ? p.e_rshift[n0 + k] : 0.f;
+        }
     }
     __syncthreads();
     if (slot >= m_slots) return;
@@ -271,6 +278,10 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
     const bool to_c0 = col < p.n_split;
     bf16* const o_base = to_c0 ? (bf16*)p.C0 + col : (bf16*)p.C + col;
     const uint32_t o_ld = (uint32_t)(to_c0 ? p.ldc0 : p.ldc);
+    // block-tail epilogue: relu(scale*c + shift + residual) on the staged rows; the residual rows of a 16-row group are asked
+    // for before the group is staged
+    constexpr bool tail = TAIL;
+    const bf16* __restrict__ e_res = (const bf16*)p.e_res;
 
     // ---- fill the ring: TA tiles
     static_for<0, TA>([&](auto tc) {
@@ -347,6 +358,20 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
             const long m_base = c_tile * TR;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
+                const long mrow0 = m_base + j * 16;                  // scalar
+                long left = M - mrow0;
+                const int rows_here = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+                const long toff = to_c0 ? mrow0 * p.ldc0 : mrow0 * p.ldc;
+                bf16x8 rres[TAIL ? RIT : 1];
+                if constexpr (TAIL) {
+                    if (tail) {
+#pragma unroll
+                        for (int rr = 0; rr < RIT; ++rr) {
+                            const int row = rr * RPP + o_rsub;
+                            rres[rr] = (o_active && row < rows_here) ? *reinterpret_cast<const bf16x8*>(e_res + (mrow0 + row) * p.e_ldres + col) : zero8();
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     bf16x4 o;
@@ -356,15 +381,32 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const long mrow0 = m_base + j * 16;                  // scalar
-                long left = M - mrow0;
-                const int rows_here = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-                const long toff = to_c0 ? mrow0 * p.ldc0 : mrow0 * p.ldc;
 #pragma unroll
                 for (int rr = 0; rr < RIT; ++rr) {
                     const int row = rr * RPP + o_rsub;
                     if (o_active && row < rows_here) {
-                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * SRS + o_chunk * 16);
+                        bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + row * SRS + o_chunk * 16);
+                        if constexpr (TAIL) {
+                            if (tail) {                 // the arithmetic of bn_act_residual_kernel, in its order
+                                float f[8], r[8], a[8], b[8];
+                                unpack8(v, f);
+                                unpack8(rres[rr], r);
+                                load8f(epi_l + o_chunk * 8, a); load8f(epi_l + NB + o_chunk * 8, b);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] = f[e] * a[e] + b[e];
+                                if (p.e_rscale) {
+                                    load8f(epi_l + 2 * NB + o_chunk * 8, a); load8f(epi_l + 3 * NB + o_chunk * 8, b);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) f[e] += r[e] * a[e] + b[e];
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) f[e] += r[e];
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf(f[e], 0.f);
+                                if (col < p.e_slice_n) *reinterpret_cast<bf16x8*>((bf16*)p.e_slice + (mrow0 + row) * p.e_slice_n + col) = v;
+                            }
+                        }
                         *reinterpret_cast<bf16x8*>(o_base + toff + __umul24((uint32_t)row, o_ld)) = v;
                         if (stats) {
 #pragma unroll
@@ -415,9 +457,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_stream_wg_kernel(const ste
     gemm_stream_body<NI, WAVES, PRO, NK, TA, J, true>(p, row_tiles, n_slices, m_slots, dv);
 }
 
+// the same with the block-tail epilogue (see gemm_stream_body)
+template <int NI, int WAVES, int PRO, int NK, int TA, int J>
+__global__ __launch_bounds__(WAVES * 64) void gemm_stream_tail_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
+                                                                      StreamDivs dv) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false, true>(p, row_tiles, n_slices, m_slots, dv);
+}
+
 // Workgroups of one instantiation resident per CU at a given dynamic LDS size (queried once; the LDS size is fixed by
 // the template arguments).  Entry points may be called from any host thread: the cache sits behind a mutex.
-template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG>
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG, bool TAIL>
 static int stream_residency(size_t lds) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
@@ -429,6 +478,10 @@ static int stream_residency(size_t lds) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>, WAVES * 64, lds);
+        } else if constexpr (TAIL) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_tail_kernel<NI, WAVES, PRO, NK, TA, J>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_tail_kernel<NI, WAVES, PRO, NK, TA, J>, WAVES * 64, lds);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -440,14 +493,14 @@ static int stream_residency(size_t lds) {
     return per_cu;
 }
 
-template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG = false>
+template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG = false, bool TAIL = false>
 static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs& dv) {
     constexpr int NB = NI * 16, K = NK * 32;
-    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + 2 * NB) * sizeof(float) +
+    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + 6 * NB) * sizeof(float) +
                        (WG ? (size_t)WAVES * (K / 16 + NB / 16) * 1024 : 0);
     const int n_slices = a->N / NB;
     const int row_tiles = stes_div_up(a->M, 16 * J);
-    const int per_cu = stream_residency<NI, WAVES, PRO, NK, TA, J, WG>(lds);
+    const int per_cu = stream_residency<NI, WAVES, PRO, NK, TA, J, WG, TAIL>(lds);
     // one resident set of workgroups: further ones would only add statistics atomics and weight-slice loads
     int m_slots = stes_div_up(row_tiles, WAVES);
     const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;
@@ -455,6 +508,9 @@ static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs
     const int grid = stes_div_up(m_slots, 8) * n_slices * 8;
     if constexpr (WG)
         hipLaunchKernelGGL((gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
+                           m_slots, dv);
+    else if constexpr (TAIL)
+        hipLaunchKernelGGL((gemm_stream_tail_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
                            m_slots, dv);
     else
         hipLaunchKernelGGL((gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
@@ -464,6 +520,12 @@ static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs
 template <int NI, int WAVES, int PRO>
 static bool launch_k(const stes_gemm_args* a, hipStream_t stream, const StreamDivs& dv) {
     // ring: K = 320 one 16-row tile (10 k-steps) ahead; K = 128 one 32-row tile; K = 64 two; K = 32 four
+    if (a->e_scale) {           // block-tail epilogue: the last 1x1 conv of a stage-1, -2 or -3 bottleneck (BatchNorm + ReLU + gate prologue)
+        if constexpr (PRO == 1 && NI == 10) { if (a->K == 320) { launch<NI, WAVES, PRO, 10, 1, 1, false, true>(a, stream, dv); return true; } }
+        if constexpr (PRO == 1 && NI == 8) { if (a->K == 128) { launch<NI, WAVES, PRO, 4, 1, 2, false, true>(a, stream, dv); return true; } }
+        if constexpr (PRO == 1 && NI == 4) { if (a->K == 64) { launch<NI, WAVES, PRO, 2, 2, 2, false, true>(a, stream, dv); return true; } }
+        return false;
+    }
     switch (a->K) {
         case 320:
             if (a->wg_dw) return false;
@@ -493,6 +555,7 @@ int stes_stream_slice(const stes_gemm_args* a) {
                       (a->n_split == 0 || (a->n_split % 8 == 0 && a->ldc0 % 8 == 0)) &&
                       // epilogue options live in the tiled kernels only
                       !a->relu_mask && !a->bias && a->act == 0 && (a->out_scale == 0.f || a->out_scale == 1.f) &&
+                      (!a->e_scale || (!a->wg_dw && !a->col_sum && a->n_split == 0)) &&
                       // the gate rows [2][K] f32 share the wave's staging buffer; a tile spans at most two images
                       (!a->a_scale || 8 * a->K <= 16 * (nb * 2 + 16)) && (!a->a_gate || (a->a_scale && a->gate_group >= 32)) &&
                       (long)a->M * (a->ldc > a->ldc0 ? a->ldc : a->ldc0) < (1L << 40);

@@ -188,16 +188,25 @@ class Block:
         se = self.se
         lib.gemm(self.pooled, self.se1.w_bf, self.hidden, self.N, self.rd, cmid, bias=se.fc1.bias, act=1)
         lib.gemm(self.hidden, self.se2.w_bf, self.segate, self.N, cmid, self.rd, bias=se.fc2.bias, act=2)
-        lib.gemm(self.c2, self.l3.w_bf, self.c3, Mo, cout, cmid, scale=self.bn2.scale, shift=self.bn2.shift, relu=True,
-                 gate=self.segate, gate_group=HWo, stats=st(self.bn3))
+        def shortcut():
+            if self.down:
+                rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
+                lib.gemm(a_src, self.ld.w_bf, self.sc, Mo, cout, cin, rowmap=rowmap, stats=st(self.bnd))
+                self.bnd.finalize(Mo, train)
+                return self.sc, self.bnd.scale, self.bnd.shift
+            return a_src, None, None
+        kw3 = dict(scale=self.bn2.scale, shift=self.bn2.shift, relu=True, gate=self.segate, gate_group=HWo)
+        if not train and lib.gemm_has_tail(Mo, cout, cmid):
+            # evaluation: conv3.bn is a fixed affine map, so relu(bn3(conv3) + shortcut) leaves the conv3 GEMM's store phase
+            # and the raw conv3 output never exists (one pass over the block output less)
+            res, rs, rb = shortcut()
+            self.bn3.finalize(Mo, train)
+            slc = (nxt.Xc, nxt.fold) if nxt is not None and nxt.kind == "gsm" else (None, 0)
+            lib.gemm(self.c2, self.l3.w_bf, self.out, Mo, cout, cmid, tail=(self.bn3.scale, self.bn3.shift, res, rs, rb) + slc, **kw3)
+            return self.out
+        lib.gemm(self.c2, self.l3.w_bf, self.c3, Mo, cout, cmid, stats=st(self.bn3), **kw3)
         self.bn3.finalize(Mo, train)
-        if self.down:
-            rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
-            lib.gemm(a_src, self.ld.w_bf, self.sc, Mo, cout, cin, rowmap=rowmap, stats=st(self.bnd))
-            self.bnd.finalize(Mo, train)
-            res, rs, rb = self.sc, self.bnd.scale, self.bnd.shift
-        else:
-            res, rs, rb = a_src, None, None
+        res, rs, rb = shortcut()
         e.bn_act(self.c3, self.bn3, res, rs, rb, self.out, nxt, train, Mo, cout)
         return self.out
 

@@ -40,7 +40,9 @@ GemmArgs = _struct("GemmArgs", [
     ("M", _I64), ("N", _I32), ("K", _I32), ("out_scale", _F32),
     ("a_raw", _P), ("bn_alpha", _P), ("bn_beta", _P), ("bn_delta", _P), ("a_out", _P), ("lda_out", _I64),
     ("wg_q", _P), ("wg_ldq", _I64), ("wg_q0", _P), ("wg_ldq0", _I64), ("wg_k0", _I32), ("wg_perm_fold", _I32),
-    ("wg_dw", _P), ("wg_lddw", _I64), ("wg_map_stride", _I32)])
+    ("wg_dw", _P), ("wg_lddw", _I64), ("wg_map_stride", _I32),
+    ("e_scale", _P), ("e_shift", _P), ("e_res", _P), ("e_ldres", _I64), ("e_rscale", _P), ("e_rshift", _P),
+    ("e_slice", _P), ("e_slice_n", _I32)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -242,6 +244,11 @@ def gemm_fuses_wgrad(M, N, K):
     return (K, N) == (64, 32) and M >= 8192
 
 
+def gemm_has_tail(M, N, K):
+    """Shapes for which stes_gemm applies the block-tail epilogue (the last 1x1 conv of a stage-1, -2 or -3 bottleneck)."""
+    return (N, K) in ((64, 64), (128, 128), (320, 320)) and M >= 8192
+
+
 def _gemm_kernel(a):
     """Which kernel stes_gemm dispatches to (the rules in stes_gemm_stream.hip and stes_gemm.hip)."""
     nb = _stream_slice(a.N)
@@ -250,7 +257,7 @@ def _gemm_kernel(a):
                  and not a.relu_mask and not a.bias and a.act == 0 and a.out_scale in (0.0, 1.0)
                  and (not a.a_scale or 8 * a.K <= 16 * (nb * 2 + 16)) and (not a.a_gate or (a.a_scale and a.gate_group >= 32)))
     if stream_ok:
-        return ("gemm_stream_wg_kernel" if a.wg_dw else "gemm_stream_kernel") + "<%d, %d, %d, %d, %d, %d>" % (
+        return ("gemm_stream_wg_kernel" if a.wg_dw else "gemm_stream_tail_kernel" if a.e_scale else "gemm_stream_kernel") + "<%d, %d, %d, %d, %d, %d>" % (
             (nb // 16, 8 if nb >= 128 else 4, pro) + _RING[a.K])
     if (not a.a_scale and not a.a_gate and a.k0 == 0 and a.map_stride <= 1 and not a.col_sum and a.n_split == 0
             and a.M * a.N * a.K <= (1 << 28) and a.M <= 16 * 65535):
@@ -263,7 +270,7 @@ def _gemm_kernel(a):
 def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, k0=0,
          scale=None, shift=None, relu=False, gate=None, gate_group=0, rowmap=None,
          bias=None, act=0, stats=None, relu_mask=None, ldmask=0, C0=None, ldc0=0, n_split=0, out_scale=0.0,
-         bn_bwd=None, wgrad_fused=None):
+         bn_bwd=None, wgrad_fused=None, tail=None):
     """C = act(pro(A) W^T + bias); see stes_gemm in include/stes.h.  bn_bwd = (raw, (alpha, beta, delta), a_out | None);
     wgrad_fused = (Q, dW, Q0 | None, ldq0, k0, perm_fold[, rowmap]): the layer's weight gradient in the same launch
     (gemm_fuses_wgrad); rowmap = (stride, Ho, Wo, Hi, Wi) reads Q's rows through a strided 1x1 conv's pixel map."""
@@ -292,8 +299,14 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
         a.wg_dw, a.wg_lddw = ptr(dw), N
         if len(wgrad_fused) > 6 and wgrad_fused[6] is not None:
             a.wg_map_stride, a.Ho, a.Wo, a.Hi, a.Wi = wgrad_fused[6]
+    if tail is not None:        # (scale, shift, res, res_scale | None, res_shift | None, slice | None, slice_n): block-tail epilogue
+        es, eb, res, rs, rb, slc, slc_n = tail
+        a.e_scale, a.e_shift, a.e_res, a.e_ldres, a.e_rscale, a.e_rshift = ptr(es), ptr(eb), ptr(res), N, ptr(rs), ptr(rb)
+        a.e_slice, a.e_slice_n = ptr(slc), (slc_n if slc is not None else 0)
     if TIMING is not None:
         byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
+        if a.e_scale:
+            byt += 2 * a.M * (a.N + a.e_slice_n)
         if a.wg_dw:
             byt, fl = byt + 2 * a.M * a.N, 2 * fl
         _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))

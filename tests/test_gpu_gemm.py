@@ -350,3 +350,42 @@ def test_wgrad_bn_backward_prologue_equals_apply_then_wgrad(N1, N2):
     if N2 > 64:
         with pytest.raises(lib.StesError):
             lib.wgrad(dD, dQ, got, M, 128, N2, ldq=ldq, bn_bwd=(dR, coef))
+
+
+@pytest.mark.parametrize("N,K,down,fold", [(64, 64, True, 16), (128, 128, False, 32), (320, 320, False, 80), (320, 320, True, 0)])
+def test_gemm_block_tail_epilogue_equals_gemm_then_bn_act_residual(N, K, down, fold):
+    """Evaluation forward of a bottleneck's last 1x1 conv: relu(bn3(conv3) + shortcut) from the GEMM's store phase, with the
+    next block's compact gated-shift slice, against the two-launch form (GEMM writing the raw product, stes_bn_act_residual
+    reading it) bit for bit -- identity and BatchNorm'ed shortcut, ragged row count."""
+    from spot_amd import lib
+    n_img, HW = 3, 53 * 52
+    M = n_img * HW
+    g = torch.Generator().manual_seed(N + K + fold)
+    X, W, R = _bf(M, K, g=g), _bf(N, K, g=g, scale=K ** -0.5), _bf(M, N, g=g)
+    scale, shift = dev(torch.rand(K, generator=g) + 0.5), dev(torch.randn(K, generator=g) * 0.3)
+    gate = dev(torch.rand(n_img, K, generator=g))
+    es, eb = dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g) * 0.3)
+    rs, rb = (dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g) * 0.3)) if down else (None, None)
+    dX, dW_, dR = dev(X), dev(W), dev(R)
+    kw = dict(scale=scale, shift=shift, relu=True, gate=gate, gate_group=HW)
+    assert lib.gemm_has_tail(M, N, K)
+    c3 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(dX, dW_, c3, M, N, K, **kw)
+    out_ref = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+    slc_ref = torch.full((M, max(fold, 8)), 4.0, dtype=torch.bfloat16, device="cuda")
+    lib.call("stes_bn_act_residual", lib.ptr(c3), lib.ptr(es), lib.ptr(eb), lib.ptr(dR), lib.ptr(rs), lib.ptr(rb), lib.ptr(out_ref), None, None,
+             fold, lib.ptr(slc_ref) if fold else None, M, N, None)
+    out = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+    slc = torch.full((M, max(fold, 8)), 6.0, dtype=torch.bfloat16, device="cuda")
+    lib.TIMING = []
+    try:
+        lib.gemm(dX, dW_, out, M, N, K, tail=(es, eb, dR, rs, rb, slc if fold else None, fold), **kw)
+        assert lib.TIMING[0][0].startswith("gemm_stream_tail_kernel<")
+    finally:
+        lib.TIMING = None
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16))
+    if fold:
+        assert torch.equal(slc.view(torch.int16), slc_ref.view(torch.int16))
+    with pytest.raises(lib.StesError):            # a shape outside the three: refused
+        lib.gemm(dX, dW_, out, M, N, K, tail=(es, eb, dR, rs, rb, None, 0), stats=(torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")), **kw)
