@@ -72,10 +72,12 @@ typedef struct {
     float* wg_dw; int64_t wg_lddw; int32_t wg_map_stride;
     /* Block-tail epilogue (optional; streaming shapes, bf16 output, no statistics, no split output): with e_scale / e_shift [N]
      * the value stored at C[m,n] is relu(e_scale[n]*c + e_shift[n] + r) with c the bf16-rounded product and r = e_res[m,n]
-     * (bf16, leading dimension e_ldres), or e_rscale[n]*e_res[m,n] + e_rshift[n] when e_rscale is given; columns
+     * (bf16, leading dimension e_ldres), or e_rscale[n]*e_res[m,n] + e_rshift[n] when e_rscale is given, or nothing when
+     * e_res is NULL (the stem: BatchNorm + ReLU only); columns
      * [0, e_slice_n) of the result are also copied to the compact tensor e_slice [M][e_slice_n].  This is
      * stes_bn_act_residual applied to this product without the product's trip through memory, for evaluation, where the
-     * BatchNorm over the product is a fixed affine map (timm Bottleneck: conv3.bn + shortcut + act3).                       */
+     * BatchNorm over the product is a fixed affine map (timm Bottleneck: conv3.bn + shortcut + act3; stem bn + act).
+     * Built for (N, K) = (64, 64), (128, 128), (320, 320) with the BatchNorm + ReLU (+ gate) prologue and (32, 32) without.  */
     const float* e_scale; const float* e_shift; const uint16_t* e_res; int64_t e_ldres; const float* e_rscale; const float* e_rshift;
     uint16_t* e_slice; int32_t e_slice_n;
 } stes_gemm_args;

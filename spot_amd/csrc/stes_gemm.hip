@@ -858,10 +858,10 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
                STES_ERR_ARG, "stes_gemm: the fused weight gradient needs the BatchNorm-backward prologue, Q and no a_out");
     STES_CHECK(!a->wg_dw || a->wg_map_stride <= 1 || (a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0 && a->M % ((long)a->Ho * a->Wo) == 0),
                STES_ERR_ARG, "stes_gemm: row map dims of the fused weight gradient's Q");
-    STES_CHECK(!a->e_scale || (a->e_shift && a->e_res && a->e_ldres % 8 == 0 && a->e_ldres >= a->N && !a->col_sum && !a->c_f32 && a->n_split == 0 &&
+    STES_CHECK(!a->e_scale || (a->e_shift && (!a->e_res || (a->e_ldres % 8 == 0 && a->e_ldres >= a->N)) && (a->e_res || !a->e_rscale) && !a->col_sum && !a->c_f32 && a->n_split == 0 &&
                                (a->e_rscale == nullptr) == (a->e_rshift == nullptr) && a->e_slice_n % 8 == 0 && a->e_slice_n <= a->N &&
                                (a->e_slice_n == 0 || a->e_slice)),
-               STES_ERR_ARG, "stes_gemm: the block-tail epilogue needs shift and residual, bf16 output, no statistics and no split output");
+               STES_ERR_ARG, "stes_gemm: the block-tail epilogue needs scale and shift, bf16 output, no statistics and no split output");
     if (stes_gemm_stream(a, stream)) {
         STES_LAUNCH_CHECK();
         return STES_OK;

@@ -368,7 +368,7 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
 #pragma unroll
                         for (int rr = 0; rr < RIT; ++rr) {
                             const int row = rr * RPP + o_rsub;
-                            rres[rr] = (o_active && row < rows_here) ? *reinterpret_cast<const bf16x8*>(e_res + (mrow0 + row) * p.e_ldres + col) : zero8();
+                            rres[rr] = (e_res && o_active && row < rows_here) ? *reinterpret_cast<const bf16x8*>(e_res + (mrow0 + row) * p.e_ldres + col) : zero8();
                         }
                     }
                 }
@@ -398,7 +398,7 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
                                     load8f(epi_l + 2 * NB + o_chunk * 8, a); load8f(epi_l + 3 * NB + o_chunk * 8, b);
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) f[e] += r[e] * a[e] + b[e];
-                                } else {
+                                } else if (e_res) {
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) f[e] += r[e];
                                 }
@@ -524,6 +524,8 @@ static bool launch_k(const stes_gemm_args* a, hipStream_t stream, const StreamDi
         if constexpr (PRO == 1 && NI == 10) { if (a->K == 320) { launch<NI, WAVES, PRO, 10, 1, 1, false, true>(a, stream, dv); return true; } }
         if constexpr (PRO == 1 && NI == 8) { if (a->K == 128) { launch<NI, WAVES, PRO, 4, 1, 2, false, true>(a, stream, dv); return true; } }
         if constexpr (PRO == 1 && NI == 4) { if (a->K == 64) { launch<NI, WAVES, PRO, 2, 2, 2, false, true>(a, stream, dv); return true; } }
+        // the stem: BatchNorm + ReLU of the 3x3 stem conv (K = 32 patch columns), no residual
+        if constexpr (PRO == 0 && NI == 2) { if (a->K == 32) { launch<NI, WAVES, PRO, 1, 4, 2, false, true>(a, stream, dv); return true; } }
         return false;
     }
     switch (a->K) {

@@ -721,10 +721,16 @@ class Engine:
         else:
             lib.call("stes_im2col_stem", p(x), p(self.patches), N, Cin, H, W)
         st = (self.bn0.sum, self.bn0.sumsq) if train else None
-        lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
-        self.bn0.finalize(self.M0, train)
         blocks = self.blocks
-        self.bn_act(self.c0, self.bn0, None, None, None, self.X0, blocks[0], train, self.M0, 32)
+        if not train and lib.gemm_has_tail(self.M0, 32, 32):
+            # evaluation: stem BatchNorm + ReLU (and the first block's gated-shift slice) in the stem GEMM's store phase
+            self.bn0.finalize(self.M0, train)
+            slc = (blocks[0].Xc, blocks[0].fold) if blocks[0].kind == "gsm" else (None, 0)
+            lib.gemm(self.patches, self.stem.w_bf, self.X0, self.M0, 32, 32, tail=(self.bn0.scale, self.bn0.shift, None, None, None) + slc)
+        else:
+            lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
+            self.bn0.finalize(self.M0, train)
+            self.bn_act(self.c0, self.bn0, None, None, None, self.X0, blocks[0], train, self.M0, 32)
         X = self.X0
         for i, blk in enumerate(blocks):
             X = blk.forward(X, train, blocks[i + 1] if i + 1 < len(blocks) else None)

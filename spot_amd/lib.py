@@ -246,7 +246,7 @@ def gemm_fuses_wgrad(M, N, K):
 
 def gemm_has_tail(M, N, K):
     """Shapes for which stes_gemm applies the block-tail epilogue (the last 1x1 conv of a stage-1, -2 or -3 bottleneck)."""
-    return (N, K) in ((64, 64), (128, 128), (320, 320)) and M >= 8192
+    return (N, K) in ((64, 64), (128, 128), (320, 320), (32, 32)) and M >= 8192
 
 
 def _gemm_kernel(a):
@@ -306,7 +306,7 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
     if TIMING is not None:
         byt, fl = _gemm_work(a, 4 if a.c_f32 else 2)
         if a.e_scale:
-            byt += 2 * a.M * (a.N + a.e_slice_n)
+            byt += 2 * a.M * ((a.N if a.e_res else 0) + a.e_slice_n)
         if a.wg_dw:
             byt, fl = byt + 2 * a.M * a.N, 2 * fl
         _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))

@@ -389,3 +389,24 @@ def test_gemm_block_tail_epilogue_equals_gemm_then_bn_act_residual(N, K, down, f
         assert torch.equal(slc.view(torch.int16), slc_ref.view(torch.int16))
     with pytest.raises(lib.StesError):            # a shape outside the three: refused
         lib.gemm(dX, dW_, out, M, N, K, tail=(es, eb, dR, rs, rb, None, 0), stats=(torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")), **kw)
+
+
+def test_gemm_stem_tail_epilogue_equals_gemm_then_bn_act():
+    """The stem in evaluation: relu(bn(stem conv)) and the first block's 8-channel gated-shift slice from the stem GEMM's store
+    phase (no prologue, no residual), bit for bit against GEMM + stes_bn_act_residual."""
+    from spot_amd import lib
+    M, N, K, fold = 3 * 57 * 55, 32, 32, 8
+    g = torch.Generator().manual_seed(11)
+    X, W = dev(_bf(M, K, g=g)), dev(_bf(N, K, g=g, scale=K ** -0.5))
+    es, eb = dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g) * 0.3)
+    c0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(X, W, c0, M, N, K)
+    out_ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    slc_ref = torch.empty(M, fold, dtype=torch.bfloat16, device="cuda")
+    lib.call("stes_bn_act_residual", lib.ptr(c0), lib.ptr(es), lib.ptr(eb), None, None, None, lib.ptr(out_ref), None, None, fold, lib.ptr(slc_ref),
+             M, N, None)
+    out = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+    slc = torch.full((M, fold), 6.0, dtype=torch.bfloat16, device="cuda")
+    lib.gemm(X, W, out, M, N, K, tail=(es, eb, None, None, None, slc, fold))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)) and torch.equal(slc.view(torch.int16), slc_ref.view(torch.int16))
