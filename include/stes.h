@@ -208,6 +208,14 @@ int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, int
 int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
                       const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
                       int stride, int C, void* stream);
+/* Forward for evaluation, with the squeeze of the squeeze-excite block behind it (timm SEModule: x.mean((2, 3)) of the
+ * activated conv2 output) taken on the way out: pool_out[n][c] (bf16) = mean over the image of
+ * relu(pool_scale[c]*out + pool_shift[c]), pool_scale / pool_shift being conv2's BatchNorm folded from its running statistics.
+ * Equals stes_conv3x3g_fwd followed by stes_chan_pool up to the order of the fp32 sum (fixed, independent of the batch);
+ * images too large for the LDS window kernel: STES_ERR_UNSUPPORTED (run the two separately).                               */
+int stes_conv3x3g_fwd_pool(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
+                           const float* in_shift, const float* pool_scale, const float* pool_shift, uint16_t* pool_out,
+                           int N, int Hi, int Wi, int Ho, int Wo, int stride, int C, void* stream);
 /* Input gradient.  With mask_raw (the raw conv1 output [N*Hi*Wi][C] whose BatchNorm+ReLU fed this convolution) the result is
  * multiplied by [mask_scale*raw + mask_shift > 0] and the BatchNorm-backward sums s_dy[c] += sum din, s_dyr[c] += sum din*raw
  * are accumulated (atomics; caller zeroes), replacing a stes_bn_bwd_reduce pass.                                         */

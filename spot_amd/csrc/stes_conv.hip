@@ -157,11 +157,17 @@ constexpr int CONV_NG = 5;             // fragment groups per step: at most 15 f
 constexpr int CONV_MAXP = 196;         // output pixels per step (host side keeps RS * Wd below this)
 static_assert(CONV_NF * CONV_NG * 16 >= CONV_MAXP, "fragment groups must cover a step");
 
-template <int STRIDE, bool FLIP>
+// POOL (forward, evaluation): the squeeze of the squeeze-excite block that follows, pool_out[n][c] = pool_norm * sum over the
+// image of relu(pool_scale[c]*y + pool_shift[c]) on the rounded outputs y (the BatchNorm over y is a fixed affine map there),
+// so the separate pooling pass does not read y again.  A workgroup owns whole images of its 64 channels: no atomics, and the
+// sum is taken in a fixed order (per thread over its pixels, lanes by xor butterfly, the four waves in order).
+template <int STRIDE, bool FLIP, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
                                                                bf16* __restrict__ dst, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* col_sum, float* col_sumsq,
-                                                               const bf16* __restrict__ mask_raw, RowsGeom gm) {
+                                                               const bf16* __restrict__ mask_raw, RowsGeom gm,
+                                                               const float* __restrict__ pool_scale, const float* __restrict__ pool_shift,
+                                                               bf16* __restrict__ pool_out, float pool_norm) {
     // FLIP with mask_raw: the result is the gradient at a ReLU(BatchNorm(raw)) output; it is masked with
     // [scale*raw + shift > 0] on its way out and the BatchNorm-backward sums (sum dy -> col_sum, sum dy*raw -> col_sumsq)
     // are accumulated here, which saves the separate reduction pass over both tensors.
@@ -221,6 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
         *reinterpret_cast<bf16x8*>(ring + r * ROWB + (side ? (Ws + 1) * PSB : 0) + ch * 16) = zero8();
     }
     if (tid < 128) red[tid] = 0.f;
+    if constexpr (POOL) {                                // red holds the pooling affine instead of statistics
+        if (tid < 64) { red[tid] = pool_scale[cb * 64 + tid]; red[64 + tid] = pool_shift[cb * 64 + tid]; }
+    }
 
     const bf16* img = nullptr;                           // this image, this channel block (uniform)
     bf16x8 regs[CONV_MAXI];
@@ -388,11 +397,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
                 continue;
             }
             *reinterpret_cast<bf16x8*>(out + (long)px * C) = v;
-            if (stats) {
+            if constexpr (POOL) {
+                float a[8], b[8];
+                load8f(red + chunk * 8, a); load8f(red + 64 + chunk * 8, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ssum[e] += fmaxf((float)v[e] * a[e] + b[e], 0.f);
+            } else if (stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float fv = (float)v[e]; ssum[e] += fv; ssq[e] += fv * fv; }
             }
         }
+    }
+    if constexpr (POOL) {                                // this image's pooled values
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = ssum[e];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            ssum[e] = t;                                 // lanes with the same 8 channels hold the wave's sum
+        }
+        __syncthreads();                                 // the store phase no longer reads the staging buffer
+        float* ps = reinterpret_cast<float*>(stage);     // [4 waves][64 channels]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ps[wave * 64 + lane * 8 + e] = ssum[e];
+        }
+        __syncthreads();
+        if (tid < 64) pool_out[(long)n * C + cb * 64 + tid] = (bf16)((((ps[tid] + ps[64 + tid]) + ps[128 + tid]) + ps[192 + tid]) * pool_norm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[e] = 0.f;
     }
     }
     if (stats) {
@@ -877,7 +909,8 @@ extern "C" int stes_pack_conv3x3g(const float* w, uint16_t* wp_fwd, uint16_t* wp
 
 static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16_t* dst, const float* scale, const float* shift,
                        float* col_sum, float* col_sumsq, const uint16_t* mask_raw, int N, int Hi, int Wi, int Ho, int Wo, int stride,
-                       int C, void* stream) {
+                       int C, void* stream, const float* pool_scale = nullptr, const float* pool_shift = nullptr,
+                       uint16_t* pool_out = nullptr, float pool_norm = 0.f) {
     STES_CHECK(src && wp && dst, STES_ERR_ARG, "stes_conv3x3g: null pointer");
     STES_CHECK(C % 64 == 0, STES_ERR_ARG, "stes_conv3x3g: channels must be a multiple of 64 (groups of 16, 4 per workgroup)");
     STES_CHECK(stride == 1 || stride == 2, STES_ERR_ARG, "stes_conv3x3g: stride must be 1 or 2");
@@ -915,6 +948,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_rows_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
                 return ok;
             }();
             // as many workgroups as are resident at once: every further one would only add device-scope statistics
@@ -937,17 +972,20 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             int per = 256 * resident / ncb; if (per < 1) per = 1; if (per > N) per = N;
             const dim3 grid(per * ncb);
             if (big_lds || lds <= 64 * 1024) {
-#define ROWS_LAUNCH(ST, FL) hipLaunchKernelGGL((conv3x3g_rows_kernel<ST, FL>), grid, dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, \
-        (bf16*)dst, scale, shift, col_sum, col_sumsq, (const bf16*)mask_raw, rg)
-                if (mode == 1) ROWS_LAUNCH(1, true);
-                else if (stride == 1) ROWS_LAUNCH(1, false);
-                else ROWS_LAUNCH(2, false);
+#define ROWS_LAUNCH(ST, FL, PL) hipLaunchKernelGGL((conv3x3g_rows_kernel<ST, FL, PL>), grid, dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, \
+        (bf16*)dst, scale, shift, col_sum, col_sumsq, (const bf16*)mask_raw, rg, pool_scale, pool_shift, (bf16*)pool_out, pool_norm)
+                if (mode == 1) ROWS_LAUNCH(1, true, false);
+                else if (pool_out && stride == 1) ROWS_LAUNCH(1, false, true);
+                else if (pool_out) ROWS_LAUNCH(2, false, true);
+                else if (stride == 1) ROWS_LAUNCH(1, false, false);
+                else ROWS_LAUNCH(2, false, false);
 #undef ROWS_LAUNCH
                 STES_LAUNCH_CHECK();
                 return STES_OK;
             }
         }
     }
+    STES_CHECK(!pool_out, STES_ERR_UNSUPPORTED, "stes_conv3x3g_fwd_pool: image too large for the LDS window kernel; run stes_chan_pool");
     if (mode == 1 && stride == 2) {
         Dgrad2Geom dg;
         dg.N = N; dg.Ho = Ho; dg.Wo = Wo; dg.Hi = Hi; dg.Wi = Wi; dg.C = C;
@@ -1012,6 +1050,14 @@ extern "C" int stes_conv3x3g_fwd(const uint16_t* in, const uint16_t* wp_fwd, uin
                                  const float* in_shift, float* col_sum, float* col_sumsq, int N, int Hi, int Wi, int Ho, int Wo,
                                  int stride, int C, void* stream) {
     return conv_launch(0, in, wp_fwd, out, in_scale, in_shift, col_sum, col_sumsq, nullptr, N, Hi, Wi, Ho, Wo, stride, C, stream);
+}
+
+extern "C" int stes_conv3x3g_fwd_pool(const uint16_t* in, const uint16_t* wp_fwd, uint16_t* out, const float* in_scale,
+                                      const float* in_shift, const float* pool_scale, const float* pool_shift, uint16_t* pool_out,
+                                      int N, int Hi, int Wi, int Ho, int Wo, int stride, int C, void* stream) {
+    STES_CHECK(pool_scale && pool_shift && pool_out, STES_ERR_ARG, "stes_conv3x3g_fwd_pool: the pooling affine and its output are required");
+    return conv_launch(0, in, wp_fwd, out, in_scale, in_shift, nullptr, nullptr, nullptr, N, Hi, Wi, Ho, Wo, stride, C, stream, pool_scale,
+                       pool_shift, pool_out, 1.0f / (float)(Ho * Wo));
 }
 
 extern "C" int stes_conv3x3g_dgrad(const uint16_t* dout, const uint16_t* wp_dgrad, uint16_t* din, const uint16_t* mask_raw,

@@ -101,6 +101,7 @@ class Block:
         self.l1 = Linear(eng, conv1.conv.weight, perm_fold=self.fold)
         self.l3 = Linear(eng, blk.conv3.conv.weight)
         self.bn1, self.bn2, self.bn3 = BN(eng, conv1.bn), BN(eng, blk.conv2.bn), BN(eng, blk.conv3.bn)
+        self.pool_fused = True
         self.w2 = blk.conv2.conv.weight
         G = self.cmid // 16
         self.wp2_f, self.wp2_d = eng.bf16(G * 5 * 512), eng.bf16(G * 5 * 512)
@@ -179,12 +180,24 @@ class Block:
         lib.gemm(a_src, self.l1.w_bf, self.c1, Mi, cmid, cin, A0=a0, lda0=k0, k0=k0, stats=st(self.bn1))
         self.bn1.finalize(Mi, train)
         s2 = st(self.bn2)
-        lib.call("stes_conv3x3g_fwd", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),
-                 p(s2[0]) if s2 else None, p(s2[1]) if s2 else None, self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
-        self.bn2.finalize(Mo, train)
         HWo = self.Ho * self.Wo
-        # squeeze-excite: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid, the two FCs as MFMA GEMMs over the frames
-        lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, None, p(self.pooled), self.N, HWo, cmid, 1.0 / HWo)
+        geo = (self.N, self.Hi, self.Wi, self.Ho, self.Wo, self.stride, cmid)
+        pooled = False
+        if not train and self.pool_fused:
+            # evaluation: conv2.bn is a fixed affine map, so the squeeze-excite squeeze is taken by the convolution on its way out
+            self.bn2.finalize(Mo, train)
+            try:
+                lib.call("stes_conv3x3g_fwd_pool", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),
+                         p(self.bn2.scale), p(self.bn2.shift), p(self.pooled), *geo)
+                pooled = True
+            except lib.StesError:
+                self.pool_fused = False             # an image too large for the window kernel: the two passes from now on
+        if not pooled:
+            lib.call("stes_conv3x3g_fwd", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),
+                     p(s2[0]) if s2 else None, p(s2[1]) if s2 else None, *geo)
+            self.bn2.finalize(Mo, train)
+            # squeeze-excite: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid, the two FCs as MFMA GEMMs over the frames
+            lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, None, p(self.pooled), self.N, HWo, cmid, 1.0 / HWo)
         se = self.se
         lib.gemm(self.pooled, self.se1.w_bf, self.hidden, self.N, self.rd, cmid, bias=se.fc1.bias, act=1)
         lib.gemm(self.hidden, self.se2.w_bf, self.segate, self.N, cmid, self.rd, bias=se.fc2.bias, act=2)

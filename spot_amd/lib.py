@@ -92,6 +92,7 @@ _SIGS = {
     "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_pack_conv3x3g": [_P, _P, _P, _I32, _I32, _P],
     "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_conv3x3g_fwd_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_conv3x3g_dgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
@@ -178,6 +179,7 @@ _KERNEL_OF = {
     "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
     # (names as a kernel trace prints them, for the shapes of the named configuration: all of them fit the LDS-window kernels)
     "stes_conv3x3g_fwd": (lambda a: "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
+    "stes_conv3x3g_fwd_pool": (lambda a: "conv3x3g_rows_kernel<%d, false, true>" % a[-2], _conv_bytes),
     "stes_conv3x3g_dgrad": (lambda a: "conv3x3g_rows_kernel<1, true>" if a[-2] == 1 else
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),

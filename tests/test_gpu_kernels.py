@@ -71,6 +71,27 @@ def test_conv3x3g(stride, H, W, C):
     close(nchw(out.cpu(), N, Ho, Wo), ref.detach(), 1e-2, 2e-2)
     close(s1, out.float().sum(0), 1e-3, 1e-2)
     close(s2, (out.float() ** 2).sum(0), 1e-3, 1e-2)
+    # forward with the squeeze-excite squeeze taken on the way out (evaluation): the same output bits, the pooled values of
+    # stes_chan_pool up to the order of the fp32 sum, the same bits again on a second run and for a sub-batch
+    ps, pb = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g) * 0.3)
+    out2 = torch.zeros_like(out)
+    pooled = torch.full((N, C), 9.0, dtype=BF, device="cuda")
+    args = (lib.ptr(dev(scale)), lib.ptr(dev(shift)), lib.ptr(ps), lib.ptr(pb))
+    try:
+        lib.call("stes_conv3x3g_fwd_pool", lib.ptr(xd), lib.ptr(wp_f), lib.ptr(out2), *args, lib.ptr(pooled), N, H, W, Ho, Wo, stride, C)
+        fused_pool = True
+    except lib.StesError:
+        fused_pool = False                # refused for images too wide for the LDS window kernel, never silently wrong
+        assert W > 150
+    want = torch.empty(N, C, dtype=BF, device="cuda")
+    lib.call("stes_chan_pool", lib.ptr(out), lib.ptr(ps), lib.ptr(pb), None, None, lib.ptr(want), N, Ho * Wo, C, 1.0 / (Ho * Wo))
+    if fused_pool:
+        pooled_b = torch.empty(1, C, dtype=BF, device="cuda")
+        lib.call("stes_conv3x3g_fwd_pool", lib.ptr(xd), lib.ptr(wp_f), lib.ptr(torch.empty_like(out)), *args, lib.ptr(pooled_b), 1, H, W, Ho, Wo, stride, C)
+        torch.cuda.synchronize()
+        assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+        close(pooled.float(), want.float(), 1e-2, 1e-3)
+        assert torch.equal(pooled_b[0].view(torch.int16), pooled[0].view(torch.int16))
     # dgrad
     din = torch.zeros(N * H * W, C, dtype=BF, device="cuda")
     gyd = dev(nhwc(gy))
