@@ -565,7 +565,8 @@ extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const
     STES_CHECK((stat_sum == nullptr) == (stat_sumsq == nullptr), STES_ERR_ARG, "stes_bn_act_residual: stats pointers");
     STES_CHECK(stat_c == 0 || stat_sum || slice_out, STES_ERR_ARG, "stes_bn_act_residual: stat_c without an output");
     static const int cap = resident_blocks(bn_act_residual_kernel);
-    const int grid = flat_grid(M, C / 8, cap);
+    // (measured per step over caps: 1.90 ms at 1,024 and 768 workgroups, 1.97 at the resident 1,280, 2.09 at 2,048, 2.29 at 512)
+    const int grid = flat_grid(M, C / 8, cap < 1024 ? cap : 1024);
     hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
                        shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C, relu_bits);
     STES_LAUNCH_CHECK();
@@ -678,6 +679,7 @@ extern "C" int stes_bn_bwd_apply(const stes_bn_bwd_args* a, void* stream) {
     if (rc) return rc;
     STES_CHECK(a->alpha && a->beta && a->delta && a->out, STES_ERR_ARG, "stes_bn_bwd_apply: coefficients/output");
     static const int cap = resident_blocks(bn_bwd_apply_kernel);
+    // (measured per step over caps: 1.75 ms at the resident 1,536 workgroups, 2.15 at 1,024, 2.54 at 768, 2.19 at 2,048)
     const int grid = flat_grid(a->M, a->C / 8, cap);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(TPB), 0, S(stream), *a, make_fastdiv(a->group > 0 ? a->group : 1));
     STES_LAUNCH_CHECK();
@@ -694,8 +696,9 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
     STES_CHECK(M <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
     STES_CHECK(!raw1 || (s_dy && s_dyr1 && (!raw2 || s_dyr2)), STES_ERR_ARG, "stes_block_in_grad: sums need their outputs");
     STES_CHECK(raw1 || !raw2, STES_ERR_ARG, "stes_block_in_grad: raw2 without raw1");
-    // (with the sums: measured flat between 1,024 and 1,280 workgroups, slower at 768 and at the 1,792 that are resident)
-    const int grid = flat_grid(M, C / 8, raw1 ? 1024 : 4096);
+    // (with the sums and two rows per trip: 177 us per launch at 512 workgroups, 181 at 768, 187 at 1,024, 196 at 1,280, 227 at
+    // 3,072; counts that are not a multiple of the 256 CUs lose 10 us: 192 at 640, 191 at 896)
+    const int grid = flat_grid(M, C / 8, raw1 ? 512 : 4096);
     const FastDiv fhw = make_fastdiv(Hi * Wi), fwi = make_fastdiv(Wi);
     if (raw1)
         hipLaunchKernelGGL(block_in_grad_kernel<true>, dim3(grid), dim3(TPB), 3 * C * sizeof(float), S(stream), (const bf16*)dY, (long)ldy,
