@@ -145,21 +145,36 @@ __global__ void chan_pool_kernel(const bf16* __restrict__ c, const float* __rest
     if (scale) { load8f(scale + c0, s); load8f(shift + c0, b); }
     const bf16* base = c + (long)n * HW * C + c0;
     const bf16* mbase = mul ? mul + (long)n * HW * C + c0 : nullptr;
-    for (int r = rg; r < HW; r += R) {
-        float v[8];
-        load8b(base + (long)r * C, v);
-        if (scale) {
+    // PU rows per trip, their loads requested together (the rows are still added in increasing order: same sums)
+    constexpr int PU = 4;
+    for (int r0 = rg; r0 < HW; r0 += PU * R) {
+        bf16x8 rv[PU], rw[PU];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * s[i] + b[i], 0.f);
+        for (int u = 0; u < PU; ++u) {
+            const int r = r0 + u * R;
+            if (r < HW) {
+                rv[u] = *reinterpret_cast<const bf16x8*>(base + (long)r * C);
+                if (mbase) rw[u] = *reinterpret_cast<const bf16x8*>(mbase + (long)r * C);
+            }
         }
-        if (mbase) {
-            float w[8];
-            load8b(mbase + (long)r * C, w);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= w[i];
+        for (int u = 0; u < PU; ++u) {
+            if (r0 + u * R >= HW) break;
+            float v[8];
+            unpack8(rv[u], v);
+            if (scale) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * s[i] + b[i], 0.f);
+            }
+            if (mbase) {
+                float w[8];
+                unpack8(rw[u], w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= w[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += v[i];
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) lds[rg * C + c0 + i] = acc[i];
@@ -194,15 +209,30 @@ __global__ void se_bwd_pool_kernel(const bf16* __restrict__ c, const float* __re
     load8f(scale + c0, s); load8f(shift + c0, b);
     const bf16* cb = c + (long)n * HW * C + c0;
     const bf16* db = dA + (long)n * HW * C + c0;
-    for (int r = rg; r < HW; r += R) {
-        float v[8], d[8];
-        load8b(cb + (long)r * C, v);
-        load8b(db + (long)r * C, d);
+    // two rows per trip, their four loads requested together (rows are still added in increasing order: same sums)
+    constexpr int PU = 2;
+    for (int r0 = rg; r0 < HW; r0 += PU * R) {
+        bf16x8 rv[PU], rd[PU];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool on = v[i] * s[i] + b[i] > 0.f;
-            const float m = on ? 1.f : 0.f, dm = on ? d[i] : 0.f;
-            a0[i] += m; a1[i] += dm; a2[i] += m * v[i]; a3[i] += dm * v[i];
+        for (int u = 0; u < PU; ++u) {
+            const int r = r0 + u * R;
+            if (r < HW) {
+                rv[u] = *reinterpret_cast<const bf16x8*>(cb + (long)r * C);
+                rd[u] = *reinterpret_cast<const bf16x8*>(db + (long)r * C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            if (r0 + u * R >= HW) break;
+            float v[8], d[8];
+            unpack8(rv[u], v);
+            unpack8(rd[u], d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool on = v[i] * s[i] + b[i] > 0.f;
+                const float m = on ? 1.f : 0.f, dm = on ? d[i] : 0.f;
+                a0[i] += m; a1[i] += dm; a2[i] += m * v[i]; a3[i] += dm * v[i];
+            }
         }
     }
 #pragma unroll
