@@ -190,7 +190,9 @@ class Block:
                 lib.call("stes_conv3x3g_fwd_pool", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),
                          p(self.bn2.scale), p(self.bn2.shift), p(self.pooled), *geo)
                 pooled = True
-            except lib.StesError:
+            except lib.StesError as err:
+                if getattr(err, "rc", 0) != lib.ERR_UNSUPPORTED:
+                    raise
                 self.pool_fused = False             # an image too large for the window kernel: the two passes from now on
         if not pooled:
             lib.call("stes_conv3x3g_fwd", p(self.c1), p(self.wp2_f), p(self.c2), p(self.bn1.scale), p(self.bn1.shift),

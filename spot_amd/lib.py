@@ -149,9 +149,14 @@ def lib():
     return _lib
 
 
+ERR_UNSUPPORTED = -3        # STES_ERR_UNSUPPORTED in include/stes.h
+
+
 def check(rc: int, what: str):
     if rc != 0:
-        raise StesError(f"{what} failed ({rc}): {lib().stes_last_error().decode()}")
+        err = StesError(f"{what} failed ({rc}): {lib().stes_last_error().decode()}")
+        err.rc = rc
+        raise err
 
 
 def stream():
