@@ -323,12 +323,22 @@ typedef struct {
 int stes_gru_forward(const stes_gru_args* a, void* stream);
 int stes_gru_backward(const stes_gru_args* a, void* stream);
 int64_t stes_gru_ws_floats(int B, int H, int backward);
+/* The one-launch recurrences wait for their peer workgroups with a bounded spin.  A wait that runs out (the workgroups of
+ * the launch were not resident together, e.g. on a GPU shared with other work) does not go unnoticed: the workgroup fills
+ * everything it produces from then on with NaN and raises a word of pinned host memory, and the NEXT stes_gru_* call of the
+ * process returns STES_ERR_LAUNCH (once) instead of launching.  stes_gru_set_spin_limit changes the bound (polls of about
+ * 64 cycles each, default 2^20; 0 makes every wait that is not already satisfied run out: a diagnostic aid). */
+int stes_gru_set_spin_limit(int limit);
 /* stes_gru_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as stes_gru_forward,
  * except that a->hstate is ignored (may be NULL): the fp32 hidden-state ping-pong buffer is a 1 MiB array inside the
  * library, one copy per GPU, so B*H <= 65536 (else STES_ERR_UNSUPPORTED).  Calls no hipMalloc/hipFree.  All calls on one
  * GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not. */
 int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream);
+/* Resolves the address of that array on the current device (what the first stes_gru_forward_noalloc call on a device
+ * does otherwise).  Address resolution is not a capturable stream operation: call this once per device before a HIP
+ * graph capture whose first use of stes_gru_forward_noalloc would be inside the capture.  No counterpart in the reference. */
+int stes_gru_noalloc_prepare(void);
 /* MinGRU recurrence, reference model/min_gru.py:76-92; pre = [gate pre-activation | candidate]; h0 [H] is the layer's
  * frozen initial-state parameter (:42,60; NULL = zeros). */
 int stes_mingru_scan_fwd(const uint16_t* pre, const float* h0, uint16_t* h, int B, int T, int H, void* stream);

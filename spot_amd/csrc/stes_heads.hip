@@ -131,15 +131,24 @@ __device__ __forceinline__ bf16x8 load_sc1(const void* ptr) {
 }
 __device__ __forceinline__ void store_sc1(void* ptr, bf16x8 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// all workgroups of the direction have published step `step - 1` (each adds one per step)
-__device__ __forceinline__ void gru_wait(unsigned* cnt, unsigned target) {
+// All workgroups of the direction have published step `step - 1` (each adds one per step).  The spin is bounded; when the
+// bound is reached (a peer workgroup not resident in time) the wait reports it instead of letting the caller read stale
+// tiles: the word at `err` (host memory that the device can write, checked by the next stes_gru_* call) is raised, and the
+// return value makes the workgroup poison everything it produces from then on (NaN), so the failure cannot pass unnoticed.
+__device__ __forceinline__ bool gru_wait(unsigned* cnt, unsigned target, int limit, unsigned* err) {
     int spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < limit) __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if (err) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
 }
 
-__global__ __launch_bounds__(512) void gru_fwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ hx) {
+__global__ __launch_bounds__(512) void gru_fwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ hx,
+                                                              int spin_limit, unsigned* err) {
     __shared__ float red[8][64][12];
     __shared__ __attribute__((aligned(16))) bf16 tile[16 * 32];
+    __shared__ int failed;
+    if (threadIdx.x == 0) failed = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int uh = wave >> 2, kq = wave & 3;               // unit half, k-step residue
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persist_kernel(const stes_gru_arg
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            if (threadIdx.x == 0) gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step);
+            if (threadIdx.x == 0 && !gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step, spin_limit, err)) failed = 1;
             __syncthreads();
             const bf16* src = hx_dir + (long)((step - 1) & 1) * nk * 512 + fr * 32 + fq * 8;
             bf16x8 fa[GRU_U];
@@ -193,6 +202,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persist_kernel(const stes_gru_arg
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     if (kq + 4 * u < nk) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], fb[u][g], acc[g], 0, 0, 0);
+            if (failed) acc[0][0] = acc[0][1] = acc[0][2] = acc[0][3] = __builtin_nanf("");
         }
 #pragma unroll
         for (int g = 0; g < 3; ++g)
@@ -308,9 +318,12 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const stes_gru_args p
 // (dr, dz, dn * r as bf16: three 16 x 32 tiles per workgroup, the A-operand tiles of k-steps g * H/32 + blk), by the same
 // write-through store / counter / sc1-load hand-off.  k-step assignment and summation order are gru_bwd_step_kernel's.
 constexpr int GRU_UB = 18;                                     // k-steps per wave: 3H / 32 / 4, H <= 768
-__global__ __launch_bounds__(512) void gru_bwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ dx) {
+__global__ __launch_bounds__(512) void gru_bwd_persist_kernel(const stes_gru_args p, unsigned* __restrict__ cnt, bf16* __restrict__ dx,
+                                                              int spin_limit, unsigned* err) {
     __shared__ float red[8][64][4];
     __shared__ __attribute__((aligned(16))) bf16 tile[3][16 * 32];
+    __shared__ int failed;
+    if (threadIdx.x == 0) failed = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int uh = wave >> 2, kq = wave & 3;
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(512) void gru_bwd_persist_kernel(const stes_gru_arg
         const int t = dir == 0 ? s : T - 1 - s;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            if (threadIdx.x == 0) gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step);
+            if (threadIdx.x == 0 && !gru_wait(my_cnt, (unsigned)gridDim.x * (unsigned)step, spin_limit, err)) failed = 1;
             __syncthreads();
             const bf16* src = dx_dir + (long)((step - 1) & 1) * nk * 512 + fr * 32 + fq * 8;
             f32x4 part[3] = {acc, acc, acc};
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(512) void gru_bwd_persist_kernel(const stes_gru_arg
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = part[0][r] + part[1][r] + part[2][r];
+            if (failed) acc[0] = acc[1] = acc[2] = acc[3] = __builtin_nanf("");
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
@@ -626,12 +640,49 @@ extern "C" int64_t stes_gru_ws_floats(int B, int H, int backward) {
     return step > one ? step : one;
 }
 
+// Time-out reporting of the one-launch recurrences (gru_wait): one word of pinned host memory that every GPU of the process
+// can write.  It is created by the first stes_gru_forward / stes_gru_backward call (not by the entry point that allocates
+// nothing, which uses it only once it exists) and read, without any synchronisation, at the start of every stes_gru_* call:
+// a raised word means an EARLIER recurrence launch of this process timed out and poisoned its outputs with NaN.
+static unsigned* g_gru_err = nullptr;
+static std::mutex g_gru_err_mu;
+static int g_gru_spin_limit = 1 << 20;
+
+static unsigned* gru_err_word(bool create) {
+    std::lock_guard<std::mutex> lock(g_gru_err_mu);
+    if (!g_gru_err && create) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+            g_gru_err = reinterpret_cast<unsigned*>(p);
+            *g_gru_err = 0u;
+        }
+    }
+    return g_gru_err;
+}
+
+static int gru_check_earlier_timeout(bool create) {
+    unsigned* w = gru_err_word(create);
+    if (w && __atomic_load_n(w, __ATOMIC_RELAXED) != 0u) {
+        __atomic_store_n(w, 0u, __ATOMIC_RELAXED);
+        return stes_set_error(STES_ERR_LAUNCH, "stes_gru: an earlier one-launch recurrence timed out waiting for its peer workgroups; "
+                                               "its outputs are NaN (the GPU was shared with work that kept them from running together)");
+    }
+    return STES_OK;
+}
+
+extern "C" int stes_gru_set_spin_limit(int limit) {
+    STES_CHECK(limit >= 0, STES_ERR_ARG, "stes_gru_set_spin_limit: negative limit");
+    g_gru_spin_limit = limit;
+    return STES_OK;
+}
+
 // the forward recurrence on the caller's stream: one launch when the workspace allows it, else one launch per step
 static int gru_forward_launch(const stes_gru_args& a, int64_t ws_floats, hipStream_t stream) {
     if (a.B <= 16 && a.H <= 32 * 4 * GRU_U && ws_floats >= gru_persist_floats(a.H, 0) && 2L * a.T * a.B * 6 * a.H < (1L << 31)) {
         unsigned* cnt = reinterpret_cast<unsigned*>(a.hstate);
         if (hipMemsetAsync(cnt, 0, 256, stream) != hipSuccess) return stes_set_error(STES_ERR_LAUNCH, "stes_gru_forward: cannot clear the step counters");
-        hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(a.H / 32, 2), dim3(512), 0, stream, a, cnt, reinterpret_cast<bf16*>(a.hstate + 64));
+        hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(a.H / 32, 2), dim3(512), 0, stream, a, cnt, reinterpret_cast<bf16*>(a.hstate + 64),
+                           g_gru_spin_limit, gru_err_word(false));
     } else {
         const dim3 grid(a.H / 16, 2, stes_div_up(a.B, 16));
         for (int s = 0; s < a.T; ++s) hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, a, s);
@@ -643,6 +694,7 @@ static int gru_forward_launch(const stes_gru_args& a, int64_t ws_floats, hipStre
 extern "C" int stes_gru_forward(const stes_gru_args* a, void* stream) {
     int rc = gru_check(a); if (rc) return rc;
     STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward: saved needs hprev_bf");
+    rc = gru_check_earlier_timeout(true); if (rc) return rc;
     return gru_forward_launch(*a, a->ws_floats, S(stream));
 }
 
@@ -656,28 +708,42 @@ constexpr int MAX_DEVICES = 64;
 static float* g_scratch_ptr[MAX_DEVICES];                      // per device, resolved on the first call there
 static std::mutex g_scratch_mu;
 
+// this device's copy of the array (resolved once per device)
+static int gru_scratch_of_device(float** out) {
+    int dev = -1;
+    STES_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES, STES_ERR_UNSUPPORTED,
+               "stes_gru_forward_noalloc: cannot identify the current device");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* sym = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sym) return stes_set_error(STES_ERR_LAUNCH, hipGetErrorString(e));
+        g_scratch_ptr[dev] = (float*)sym;
+    }
+    *out = g_scratch_ptr[dev];
+    return STES_OK;
+}
+
+extern "C" int stes_gru_noalloc_prepare(void) {
+    float* ptr = nullptr;
+    return gru_scratch_of_device(&ptr);
+}
+
 extern "C" int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream) {
     STES_CHECK(a && a->gi && a->whh && a->bhh && a->y, STES_ERR_ARG, "stes_gru_forward_noalloc: null pointer");
     STES_CHECK(a->H > 0 && a->H % 32 == 0 && a->B > 0 && a->T > 0, STES_ERR_ARG, "stes_gru_forward_noalloc: H must be a positive multiple of 32");
     STES_CHECK(!a->saved || a->hprev_bf, STES_ERR_ARG, "stes_gru_forward_noalloc: saved needs hprev_bf");
     STES_CHECK(4L * a->B * a->H <= GRU_SCRATCH_FLOATS, STES_ERR_UNSUPPORTED,
                "stes_gru_forward_noalloc: B*H exceeds the static scratch (B*H <= 65536); use stes_gru_forward with a caller workspace");
-    int dev = -1;
-    STES_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES, STES_ERR_UNSUPPORTED,
-               "stes_gru_forward_noalloc: cannot identify the current device");
-    float* ptr;
+    float* ptr = nullptr;
     {
-        std::lock_guard<std::mutex> lock(g_scratch_mu);
-        if (!g_scratch_ptr[dev]) {
-            void* sym = nullptr;
-            const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
-            if (e != hipSuccess || !sym) return stes_set_error(STES_ERR_LAUNCH, hipGetErrorString(e));
-            g_scratch_ptr[dev] = (float*)sym;
-        }
-        ptr = g_scratch_ptr[dev];
+        const int rc0 = gru_scratch_of_device(&ptr);
+        if (rc0) return rc0;
     }
     // what must start at zero (the step counters of the one-launch recurrence) is cleared by a memset node on the stream;
     // the step launches need nothing cleared: step 0 takes h = 0 without reading the buffer, step s reads what step s-1 wrote
+    const int rc = gru_check_earlier_timeout(false);
+    if (rc) return rc;
     stes_gru_args b = *a;
     b.hstate = ptr;
     return gru_forward_launch(b, GRU_SCRATCH_FLOATS, S(stream));
@@ -686,11 +752,13 @@ extern "C" int stes_gru_forward_noalloc(const stes_gru_args* a, void* stream) {
 extern "C" int stes_gru_backward(const stes_gru_args* a, void* stream) {
     int rc = gru_check(a); if (rc) return rc;
     STES_CHECK(a->saved && a->whhT && a->dy && a->dgi && a->dgh && a->dhstate && a->ld_dy >= 2 * a->H, STES_ERR_ARG, "stes_gru_backward: null pointer");
+    rc = gru_check_earlier_timeout(true); if (rc) return rc;
     if (a->B <= 16 && a->H <= 32 * 4 * GRU_U && a->ws_floats >= gru_persist_floats(a->H, 1) && 2L * a->T * a->B * 6 * a->H < (1L << 31) &&
         (long)a->B * a->T * a->ld_dy < (1L << 31)) {
         unsigned* cnt = reinterpret_cast<unsigned*>(a->dhstate);
         STES_CHECK(hipMemsetAsync(cnt, 0, 256, S(stream)) == hipSuccess, STES_ERR_LAUNCH, "stes_gru_backward: cannot clear the step counters");
-        hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(a->H / 32, 2), dim3(512), 0, S(stream), *a, cnt, reinterpret_cast<bf16*>(a->dhstate + 64));
+        hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(a->H / 32, 2), dim3(512), 0, S(stream), *a, cnt, reinterpret_cast<bf16*>(a->dhstate + 64),
+                           g_gru_spin_limit, gru_err_word(false));
     } else {
         const dim3 grid(a->H / 16, 2, stes_div_up(a->B, 16));
         for (int s = 0; s < a->T; ++s) hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, S(stream), *a, s);

@@ -211,7 +211,7 @@ class Block:
                 return self.sc, self.bnd.scale, self.bnd.shift
             return a_src, None, None
         kw3 = dict(scale=self.bn2.scale, shift=self.bn2.shift, relu=True, gate=self.segate, gate_group=HWo)
-        if not train and lib.gemm_has_tail(Mo, cout, cmid):
+        if not train and lib.gemm_has_tail(Mo, cout, cmid, gate_group=HWo):
             # evaluation: conv3.bn is a fixed affine map, so relu(bn3(conv3) + shortcut) leaves the conv3 GEMM's store phase
             # and the raw conv3 output never exists (one pass over the block output less)
             res, rs, rb = shortcut()

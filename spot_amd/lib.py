@@ -121,7 +121,7 @@ _SIGS = {
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
 EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats", "stes_wgrad_ws_floats",
-           "stes_augment_ws_floats"] + list(_SIGS)
+           "stes_augment_ws_floats", "stes_gru_set_spin_limit", "stes_gru_noalloc_prepare"] + list(_SIGS)
 
 
 def lib():
@@ -141,6 +141,10 @@ def lib():
         L.stes_wgrad_ws_floats.restype = C.c_int64
         L.stes_augment_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
         L.stes_augment_ws_floats.restype = C.c_int64
+        L.stes_gru_set_spin_limit.argtypes = [C.c_int]
+        L.stes_gru_set_spin_limit.restype = C.c_int
+        L.stes_gru_noalloc_prepare.argtypes = []
+        L.stes_gru_noalloc_prepare.restype = C.c_int
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig
@@ -254,9 +258,11 @@ def gemm_fuses_wgrad(M, N, K):
     return (K, N) == (64, 32) and M >= 8192
 
 
-def gemm_has_tail(M, N, K):
-    """Shapes for which stes_gemm applies the block-tail epilogue (the last 1x1 conv of a stage-1, -2 or -3 bottleneck)."""
-    return (N, K) in ((64, 64), (128, 128), (320, 320), (32, 32)) and M >= 8192
+def gemm_has_tail(M, N, K, gate_group=None):
+    """Shapes for which stes_gemm applies the block-tail epilogue (the last 1x1 conv of a stage-1, -2 or -3 bottleneck).
+    gate_group: rows per squeeze-excite gate row when the operand is gated; the streaming kernel, the only one with the
+    epilogue, takes gate groups of at least 32 rows (the rule in stes_gemm_stream.hip)."""
+    return (N, K) in ((64, 64), (128, 128), (320, 320), (32, 32)) and M >= 8192 and (gate_group is None or gate_group >= 32)
 
 
 def _gemm_kernel(a):

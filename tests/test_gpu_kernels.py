@@ -117,6 +117,40 @@ def test_conv3x3g(stride, H, W, C):
     close(dw, wref.grad, 1e-2, 2e-2 * math.sqrt(N * Ho * Wo))
 
 
+def test_gru_one_launch_timeout_is_loud():
+    """A wait of the one-launch GRU recurrence that runs out must not pass unnoticed: with the spin bound at zero (every wait
+    that is not already satisfied runs out) the outputs carry NaN and the next stes_gru_* call reports the failure; with
+    the bound restored the same call works again."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(5)
+    B, T, H = 4, 12, 768
+    gi = (torch.randn(B, T, 2, 3 * H, generator=g) * 0.7).to(BF).cuda()
+    whh = (torch.randn(2, 3 * H, H, generator=g) / H ** 0.5).to(BF).cuda()
+    bhh = (torch.randn(2, 3 * H, generator=g) * 0.1).cuda()
+
+    def run():
+        y = torch.zeros(B, T, 2 * H, dtype=BF, device="cuda")
+        hs = torch.zeros(lib.lib().stes_gru_ws_floats(B, H, 0), device="cuda")
+        a = lib.gru_args(gi=gi, whh=whh, whhT=None, bhh=bhh, y=y, hstate=hs, saved=None, hprev_bf=None, B=B, T=T, H=H, ws_floats=hs.numel())
+        rc = lib.lib().stes_gru_forward(C.byref(a), lib.stream())
+        torch.cuda.synchronize()
+        return rc, y
+
+    rc, good = run()
+    assert rc == 0 and bool(torch.isfinite(good.float()).all())
+    try:
+        assert lib.lib().stes_gru_set_spin_limit(0) == 0
+        rc, bad = run()
+        assert rc == 0                                         # the failure happens on the device, after the call returned
+        assert bool(torch.isnan(bad.float()).any())
+        rc, _ = run()                                          # the next call refuses, once, and names the reason
+        assert rc == -2 and b"timed out" in lib.lib().stes_last_error()
+    finally:
+        lib.lib().stes_gru_set_spin_limit(1 << 20)
+    rc, again = run()
+    assert rc == 0 and torch.equal(again.view(torch.int16), good.view(torch.int16))
+
+
 def test_im2col_stem():
     from spot_amd import lib
     g = torch.Generator().manual_seed(4)

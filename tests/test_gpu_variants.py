@@ -56,6 +56,29 @@ def test_native_16x9_clip_forward_vs_oracle():
         assert r < (2.5e-2 if k == "loc_feat" else 1e-2), (k, r)
 
 
+def test_eval_forward_on_small_maps_with_many_frames_vs_oracle():
+    """64 x 64 crops, 8 clips of 64 frames: stage 3 has 4 x 4 maps, so a squeeze-excite gate row covers 16 rows of the last
+    1x1 conv's operand, fewer than the streaming GEMM's block-tail form takes, while the row count (8,192) is one it would
+    otherwise take: the forward must fall back to the GEMM + separate tail pass, not fail."""
+    from oracle import stes_oracle as O
+    om, m = _pair("rny008_gsm", "gru", clip_len=64, seed=21)
+    x = torch.randn(8, 64, 3, 64, 64, generator=torch.Generator().manual_seed(22))
+    torch.set_num_threads(16)
+    om.eval()
+    with torch.no_grad():
+        od = om(x)
+    m._model.eval()
+    with torch.no_grad():
+        d = m._model(x.cuda())
+        d1 = m._model(x[:1].cuda())
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].cpu(), od[k])
+        print(k, r)
+        assert r < (2.5e-2 if k == "loc_feat" else 1e-2), (k, r)
+    # clips are independent units
+    assert rel(d1["im_feat"].cpu(), d["im_feat"][:1].cpu()) < 2e-3
+
+
 def test_deeper_gru_eval_vs_oracle():
     from oracle import stes_oracle as O
     om, m = _pair("rny008_gsm", "deeper_gru")
@@ -305,8 +328,9 @@ def test_sliding_window_events_match_oracle():
     oev = O.nms_events(O.filter_events_by_score(O.events_from_scores(osc, oloc, classes), 0.15), 3)
     margin = np.sort(osc, 1)[:, -1] - np.sort(osc, 1)[:, -2]
     print("min top-2 score margin in the oracle:", margin.min(), " max |score diff|:", np.abs(scores - osc).max())
-    # the claim "identical event frames" is made where the decision margins exceed the bf16 noise of the scores fourfold
-    assert margin.min() > 4 * np.abs(scores - osc).max()
+    # the claim "identical event frames" is made where no argmax can flip: two scores that each move by at most the largest
+    # score error e can only change order when they are no more than 2e apart
+    assert margin.min() > 2 * np.abs(scores - osc).max()
     got = [(e["frame"], e["label"]) for e in ev[0]["events"]]
     want = [(e["frame"], e["label"]) for e in oev]
     assert got == want

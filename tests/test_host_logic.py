@@ -182,6 +182,30 @@ def test_video_clip_layout_and_evaluate_with_a_stub_model(tmp_path):
     assert EV.evaluate(stub, ds, "VAL", classes, predict_location=False, quiet=True) == 1.0
 
 
+def test_scorer_cli_rescores_the_prediction_files(tmp_path, golden, capsys):
+    """python -m spot_amd.score_cli: a model directory with pred-test.N / pred-val.N recall files and a truth file; the numbers
+    are those of compute_mAPs before and after the windowed peak picking, the epoch is the newest test epoch's."""
+    import gzip
+    from spot_amd import score_cli as SC
+    from spot_amd.util import eval as E, score as S
+    z = golden("scores")
+    truth, pred = json.loads(str(z["truth"])), json.loads(str(z["pred"]))
+    d = tmp_path / "model"
+    os.makedirs(d)
+    for name in ("pred-test.3", "pred-test.7", "pred-val.7"):
+        with gzip.open(d / (name + ".recall.json.gz"), "wt", encoding="ascii") as fp:
+            json.dump(pred if name != "pred-test.3" else [], fp)
+    json.dump(truth, open(tmp_path / "val.json", "w"))
+    assert SC.newest_epoch(str(d), "test")[1] == 7
+    out = SC.main([str(d), "-s", "val", "--truth", str(tmp_path / "val.json"), "-t", "0", "1", "2", "--nms_window", "2"])
+    assert "pred-val.7.recall.json.gz" in capsys.readouterr().out
+    assert out["raw"][0] == S.compute_mAPs(truth, pred, [0, 1, 2], quiet=True)[0]
+    assert out["nms"][0] == S.compute_mAPs(truth, E.non_maximum_supression(pred, 2), [0, 1, 2], quiet=True)[0]
+    assert out["nms"][0] != out["raw"][0]
+    with pytest.raises(FileNotFoundError):
+        SC.newest_epoch(str(tmp_path), "test")
+
+
 def test_sliding_window_accumulator_and_sharding():
     from spot_amd import infer
     from spot_amd.util.postproc import ScoreAccumulator
