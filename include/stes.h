@@ -327,7 +327,7 @@ int64_t stes_gru_ws_floats(int B, int H, int backward);
  * the launch were not resident together, e.g. on a GPU shared with other work) does not go unnoticed: the workgroup fills
  * everything it produces from then on with NaN and raises a word of pinned host memory, and the NEXT stes_gru_* call of the
  * process returns STES_ERR_LAUNCH (once) instead of launching.  stes_gru_set_spin_limit changes the bound (polls of about
- * 64 cycles each, default 2^20; 0 makes every wait that is not already satisfied run out: a diagnostic aid). */
+ * 64 cycles each, default 2^20; 0 makes every wait run out, satisfied or not: a diagnostic aid). */
 int stes_gru_set_spin_limit(int limit);
 /* stes_gru_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as stes_gru_forward,

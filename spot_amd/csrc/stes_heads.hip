@@ -138,7 +138,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ bool gru_wait(unsigned* cnt, unsigned target, int limit, unsigned* err) {
     int spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < limit) __builtin_amdgcn_s_sleep(1);
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if (limit > 0 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     if (err) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return false;
 }

@@ -49,23 +49,22 @@ def step_fractions(fps_per_gpu):
             "hbm_frac": w["step_bytes"] * fps_per_gpu / HBM_PEAK_BPS}
 
 
-def measure_dominant_kernel(trainer, batch, steps=3):
-    """Roofline of the kernel with the largest share of the step.  Every launch of `steps` training steps is bracketed by
-    HIP events on the launch stream (spot_amd.lib.TIMING); launches are grouped by kernel, the kernel with the largest
-    summed duration is the dominant one, and achieved = sum of its launches' algorithmic bytes (every operand read once,
-    every result written once) / sum of their durations.  During this pass the weight-gradient kernels run on the main
-    stream instead of beside it (engine.OVERLAP off), so that a launch's duration is that kernel's alone and not a share of
-    a GPU it splits with another kernel.  `traffic` (HBM bytes per launch from the PMC counters) comes
-    from the committed counter run of the same command, profiles/pmc_traffic.json, when it holds this kernel."""
+def measure_dominant_kernel(run, steps=3):
+    """Roofline of the kernel with the largest share of `run()` (one training step, or one forward).  Every launch of `steps`
+    runs is bracketed by HIP events on the launch stream (spot_amd.lib.TIMING); launches are grouped by kernel, the kernel
+    with the largest summed duration is the dominant one, and achieved = sum of its launches' algorithmic bytes (every
+    operand read once, every result written once) / sum of their durations.  During this pass the weight-gradient kernels
+    run on the main stream instead of beside it (engine.OVERLAP off), so that a launch's duration is that kernel's alone and
+    not a share of a GPU it splits with another kernel.  `traffic` (HBM bytes per launch from the PMC counters) comes
+    from the committed counter run of the training step, profiles/pmc_traffic.json, when it holds this kernel."""
     import json
     import os
     from . import engine, lib
-    x, label, xy = batch
     lib.TIMING = []
     overlap, engine.OVERLAP = engine.OVERLAP, False
     try:
         for _ in range(steps):
-            trainer.step(x, label, xy)
+            run()
         torch.cuda.synchronize()
         recs = lib.TIMING
     finally:

@@ -119,7 +119,7 @@ def test_conv3x3g(stride, H, W, C):
 
 def test_gru_one_launch_timeout_is_loud():
     """A wait of the one-launch GRU recurrence that runs out must not pass unnoticed: with the spin bound at zero (every wait
-    that is not already satisfied runs out) the outputs carry NaN and the next stes_gru_* call reports the failure; with
+    runs out) the outputs carry NaN and the next stes_gru_* call reports the failure; with
     the bound restored the same call works again."""
     from spot_amd import lib
     g = torch.Generator().manual_seed(5)
