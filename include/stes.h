@@ -28,6 +28,16 @@ extern "C" {
 int stes_version(void);
 const char* stes_last_error(void);
 
+/* Deterministic mode (a test mode; no counterpart in the reference, whose float atomics inside cuDNN/MIOpen are not under
+ * its control either).  Every cross-workgroup fp32 sum of this library (BatchNorm statistics, BatchNorm-backward sums,
+ * weight gradients, bias gradients) is accumulated with float atomics, so its last bits depend on the order in which the
+ * workgroups of a launch arrive.  With a ticket (256 bytes of device memory, cleared by this call on `stream`) the
+ * workgroups of every such launch commit in block-index order and LDS accumulations run wave after wave: the same values
+ * are added in a fixed order, and two runs of the same work give the same bits.  Commits are serialised, so launches are
+ * slower.  While the mode is on, drive the library from one stream.  ticket[1] != 0 afterwards means a wait for a turn ran
+ * out (the order was not kept).  NULL turns the mode off. */
+int stes_set_deterministic(uint32_t* ticket, void* stream);
+
 /* ---------------------------------------------------------------- GEMM ----
  * C[M,N] = act( pro(A)[M,K] * W[N,K]^T + bias )      (1x1 convolutions, Linear layers)
  * pro(A)[m,k] = relu?( A[m,k] * a_scale[k] + a_shift[k] ) * a_gate[m / gate_group][k]

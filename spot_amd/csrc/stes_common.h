@@ -86,3 +86,65 @@ __device__ __forceinline__ void fdivmod(uint32_t x, const FastDiv& f, uint32_t& 
     r = x - q * f.d;
 }
 #define STES_MAX_ROWS 0x7fffffffL
+
+// ---------------------------------------------------------------- deterministic mode (stes_set_deterministic)
+// Every cross-workgroup fp32 accumulation of the library is a float atomic, whose result depends on the order in which the
+// workgroups of a launch arrive.  In deterministic mode that order is fixed: the workgroups of a launch commit their sums
+// one after the other in block-index order (a ticket word in device memory that the caller provides), and accumulations
+// inside a workgroup that use LDS atomics run wave after wave.  The values added are the same as in the normal mode; only
+// their order is pinned, so two runs of the same step give the same bits.  It is a test mode: commits are serialised.
+struct StesDet {
+    unsigned* ticket;     // nullptr: normal mode.  ticket[0]: turn counter, ticket[1]: raised when a wait ran out
+    unsigned base;        // value of the turn counter at which block 0 of this launch commits
+    unsigned pad;
+};
+// host: the ticket window of a launch of `nblocks` workgroups ({nullptr, 0} in normal mode); launches that use it must be
+// issued in the order of these calls on one stream
+StesDet stes_det_take(unsigned nblocks);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned det_block_id() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+
+// All threads of the workgroup call both.  Between them the workgroup issues its global atomics; det_leave makes sure they
+// have been performed before the next workgroup's turn starts.
+__device__ __forceinline__ void det_enter(const StesDet& d) {
+    if (!d.ticket) return;
+    if (threadIdx.x == 0) {
+        const unsigned turn = d.base + det_block_id();
+        int spins = 0;
+        while (__hip_atomic_load(d.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
+            if (++spins > (1 << 24)) { __hip_atomic_fetch_or(d.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void det_leave(const StesDet& d) {
+    if (!d.ticket) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(d.ticket, d.base + det_block_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// `stmt` (LDS float atomics of every thread): as issued in normal mode, wave after wave in deterministic mode
+#define STES_DET_LDS(det, ...)                                                                       \
+    do {                                                                                             \
+        if (!(det).ticket) { __VA_ARGS__; }                                                               \
+        else {                                                                                       \
+            const int nw_ = ((int)blockDim.x + 63) >> 6, w_ = (int)threadIdx.x >> 6;                 \
+            for (int i_ = 0; i_ < nw_; ++i_) { if (i_ == w_) { __VA_ARGS__; } __syncthreads(); }          \
+        }                                                                                            \
+    } while (0)
+// `stmt` (global float atomics that every wave issues on the same addresses): as issued in normal mode; in deterministic
+// mode wave after wave, each wave's atomics performed before the next wave starts
+#define STES_DET_WAVES(det, ...)                                                                     \
+    do {                                                                                             \
+        if (!(det).ticket) { __VA_ARGS__; }                                                               \
+        else {                                                                                       \
+            const int nw_ = ((int)blockDim.x + 63) >> 6, w_ = (int)threadIdx.x >> 6;                 \
+            for (int i_ = 0; i_ < nw_; ++i_) {                                                       \
+                if (i_ == w_) { __VA_ARGS__; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }           \
+                __syncthreads();                                                                     \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+#endif

@@ -48,7 +48,7 @@ template <int MODE, int STRIDE>   // MODE 0 forward (dst = conv output), 1 dgrad
 __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ src, const bf16* __restrict__ wp,
                                                        bf16* __restrict__ dst, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* col_sum, float* col_sumsq,
-                                                       ConvGeom gm, int n_tiles) {
+                                                       ConvGeom gm, int n_tiles, StesDet det) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float red[2][64];
     const bool active = blockIdx.y * 4 + wave < gm.G;
@@ -128,10 +128,12 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const bf16* __restrict__ 
         }
         __syncthreads();
         // one contiguous 64-channel atomic per workgroup and statistic instead of 32 four-lane ones
+        det_enter(det);
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6, c = blockIdx.y * 64 + (threadIdx.x & 63);
             if (c < gm.C) atomicAdd((which ? col_sumsq : col_sum) + c, red[which][threadIdx.x & 63]);
         }
+        det_leave(det);
     }
 }
 
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
                                                                const float* __restrict__ shift, float* col_sum, float* col_sumsq,
                                                                const bf16* __restrict__ mask_raw, RowsGeom gm,
                                                                const float* __restrict__ pool_scale, const float* __restrict__ pool_shift,
-                                                               bf16* __restrict__ pool_out, float pool_norm) {
+                                                               bf16* __restrict__ pool_out, float pool_norm, StesDet det) {
     // FLIP with mask_raw: the result is the gradient at a ReLU(BatchNorm(raw)) output; it is masked with
     // [scale*raw + shift > 0] on its way out and the BatchNorm-backward sums (sum dy -> col_sum, sum dy*raw -> col_sumsq)
     // are accumulated here, which saves the separate reduction pass over both tensors.
@@ -429,10 +431,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
     }
     }
     if (stats) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); }
+        STES_DET_LDS(det, _Pragma("unroll") for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); });
         __syncthreads();
+        det_enter(det);
         if (tid < 128) atomicAdd((tid < 64 ? col_sum : col_sumsq) + cb * 64 + (tid & 63), red[tid]);
+        det_leave(det);
     }
 }
 
@@ -450,7 +453,7 @@ template <bool BATCH>
 __global__ __launch_bounds__(256, 2) void conv3x3g_dgrad2_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wp,
                                                                  bf16* __restrict__ dx, const bf16* __restrict__ mask_raw,
                                                                  const float* __restrict__ mscale, const float* __restrict__ mshift,
-                                                                 float* s_dy, float* s_dyr, Dgrad2Geom gm) {
+                                                                 float* s_dy, float* s_dyr, Dgrad2Geom gm, StesDet det) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, q = lane >> 4;
@@ -681,10 +684,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_dgrad2_kernel(const bf16* __r
         }
     }
     if (masked) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); }
+        STES_DET_LDS(det, _Pragma("unroll") for (int e = 0; e < 8; ++e) { atomicAdd(&red[chunk * 8 + e], ssum[e]); atomicAdd(&red[64 + chunk * 8 + e], ssq[e]); });
         __syncthreads();
+        det_enter(det);
         if (tid < 128) atomicAdd((tid < 64 ? s_dy : s_dyr) + cb * 64 + (tid & 63), red[tid]);
+        det_leave(det);
     }
 }
 
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ dw, int N, int Hi, int Wi, int Ho, int Wo,
                                                              int stride, int C, int n_items, FastDiv fd_tiles, FastDiv fd_tw,
-                                                             FastDiv fd_iw) {
+                                                             FastDiv fd_iw, StesDet det) {
     // one LDS block: staging tiles while walking items, then re-used to lay the result out for coalesced atomics
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * 16 * 2 + 4 * MAX_HALO * 16 * 2];
     static_assert(sizeof(smem) >= 4608 * 4, "the result layout of two groups must fit the staging tiles");
@@ -805,6 +809,7 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
     // result -> LDS in the checkpoint layout [co][ci][tap] of the 64 channels of this workgroup, then contiguous atomics; two
     // groups at a time, so that this layout needs no more LDS than the staging tiles (24 KiB: six workgroups per CU)
     float* dst = dw + (long)gq * 9216;
+    det_enter(det);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if ((wave >> 1) == h) {
@@ -817,6 +822,7 @@ __global__ __launch_bounds__(256) void conv3x3g_wgrad_kernel(const bf16* __restr
         for (int i = tid; i < 4608; i += 256) atomicAdd(dst + h * 4608 + i, red[i]);
         __syncthreads();
     }
+    det_leave(det);
 }
 
 // ------------------------------------------------------------------ stem im2col
@@ -977,7 +983,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
             const dim3 grid(per * ncb);
             if (big_lds || lds <= 64 * 1024) {
 #define ROWS_LAUNCH(ST, FL, PL) hipLaunchKernelGGL((conv3x3g_rows_kernel<ST, FL, PL>), grid, dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, \
-        (bf16*)dst, scale, shift, col_sum, col_sumsq, (const bf16*)mask_raw, rg, pool_scale, pool_shift, (bf16*)pool_out, pool_norm)
+        (bf16*)dst, scale, shift, col_sum, col_sumsq, (const bf16*)mask_raw, rg, pool_scale, pool_shift, (bf16*)pool_out, pool_norm, \
+        col_sum ? stes_det_take(grid.x) : StesDet{nullptr, 0u, 0u})
                 if (mode == 1) ROWS_LAUNCH(1, true, false);
                 else if (pool_out && stride == 1) ROWS_LAUNCH(1, false, true);
                 else if (pool_out) ROWS_LAUNCH(2, false, true);
@@ -1020,10 +1027,10 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
         // without it the plain loop (667 vs 761 us): measured, both forms kept
         if (mask_raw)
             hipLaunchKernelGGL(conv3x3g_dgrad2_kernel<true>, dim3(per * ncb), dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst,
-                               (const bf16*)mask_raw, scale, shift, col_sum, col_sumsq, dg);
+                               (const bf16*)mask_raw, scale, shift, col_sum, col_sumsq, dg, stes_det_take(per * ncb));
         else
             hipLaunchKernelGGL(conv3x3g_dgrad2_kernel<false>, dim3(per * ncb), dim3(256), lds, S(stream), (const bf16*)src, (const bf16*)wp, (bf16*)dst,
-                               (const bf16*)mask_raw, scale, shift, col_sum, col_sumsq, dg);
+                               (const bf16*)mask_raw, scale, shift, col_sum, col_sumsq, dg, StesDet{nullptr, 0u, 0u});
         STES_LAUNCH_CHECK();
         return STES_OK;
     }
@@ -1042,7 +1049,7 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     const int cap = 4096 / gy > 1 ? 4096 / gy : 1;
     if (gx > cap) gx = cap;
 #define CONV_LAUNCH(MODE, ST) hipLaunchKernelGGL((conv3x3g_kernel<MODE, ST>), dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)src, \
-        (const bf16*)wp, (bf16*)dst, scale, shift, col_sum, col_sumsq, gm, n_tiles)
+        (const bf16*)wp, (bf16*)dst, scale, shift, col_sum, col_sumsq, gm, n_tiles, col_sum ? stes_det_take(gx * gy) : StesDet{nullptr, 0u, 0u})
     if (mode == 0) { if (stride == 1) CONV_LAUNCH(0, 1); else CONV_LAUNCH(0, 2); }
     else CONV_LAUNCH(1, 1);
 #undef CONV_LAUNCH
@@ -1093,7 +1100,8 @@ extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, con
     if (gx > 8) gx &= ~7;                      // a multiple of 8: see the kernel's item permutation
     const int IW = (TW - 1) * stride + 3;
     hipLaunchKernelGGL(conv3x3g_wgrad_kernel, dim3(gx, gy), dim3(256), 0, S(stream), (const bf16*)dout, (const bf16*)in, in_scale, in_shift,
-                       dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, make_fastdiv(th * tw), make_fastdiv(tw), make_fastdiv(IW));
+                       dw, N, Hi, Wi, Ho, Wo, stride, C, n_items, make_fastdiv(th * tw), make_fastdiv(tw), make_fastdiv(IW),
+                       stes_det_take(gx * gy));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -98,7 +98,7 @@ struct Epilogue {
         return ob;
     }
     // the workgroup's statistics: one contiguous 64-channel atomic per statistic
-    __device__ __forceinline__ void commit(float* s0, float* s1, int cb, float (*red)[64]) {
+    __device__ __forceinline__ void commit(float* s0, float* s1, int cb, float (*red)[64], const StesDet& det) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -106,7 +106,9 @@ struct Epilogue {
             if ((lane & 15) == 0) { red[0][wave * 16 + (lane >> 4) * 4 + i] = a; red[1][wave * 16 + (lane >> 4) * 4 + i] = b; }
         }
         __syncthreads();
+        det_enter(det);
         if (tid < 128) atomicAdd((tid < 64 ? s0 : s1) + cb * 64 + (tid & 63), red[tid >> 6][tid & 63]);
+        det_leave(det);
     }
     // the image's pooled values (a wave owns its 16 channels of the image: fixed order, no atomics)
     __device__ __forceinline__ void pool_out(bf16* __restrict__ dst, float norm) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3g_strip_kernel(const bf16* __re
                                                                 const float* __restrict__ shift, float* col_sum, float* col_sumsq,
                                                                 StripGeom gm, const float* __restrict__ pool_scale,
                                                                 const float* __restrict__ pool_shift, bf16* __restrict__ pool_dst,
-                                                                float pool_norm) {
+                                                                float pool_norm, StesDet det) {
     __shared__ float red[2][64];
     constexpr bool POOL = EPI == EPI_POOL;
     constexpr int D = S1_D;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3g_strip_kernel(const bf16* __re
             }
         }
     }
-    if constexpr (EPI == EPI_STATS) ep.commit(col_sum, col_sumsq, cb, red);
+    if constexpr (EPI == EPI_STATS) ep.commit(col_sum, col_sumsq, cb, red, det);
 }
 
 template <typename K>
@@ -318,8 +320,9 @@ int stes_conv_strip_launch(const uint16_t* src, const uint16_t* wp, uint16_t* ds
     hipStream_t st = (hipStream_t)stream;
     const bf16* s = (const bf16*)src; const bf16* w = (const bf16*)wp; bf16* d = (bf16*)dst;
     const int epi = pool ? EPI_POOL : (col_sum ? EPI_STATS : EPI_NONE);
+    const StesDet det = epi == EPI_STATS ? stes_det_take(grid.x * grid.y) : StesDet{nullptr, 0u, 0u};
 #define STRIP_LAUNCH(AF, EP) hipLaunchKernelGGL((conv3x3g_strip_kernel<AF, EP>), grid, block, 0, st, s, w, d, scale, shift, col_sum, \
-        col_sumsq, gm, pool_scale, pool_shift, (bf16*)pool_out, pool_norm)
+        col_sumsq, gm, pool_scale, pool_shift, (bf16*)pool_out, pool_norm, det)
     if (scale) { if (epi == EPI_POOL) STRIP_LAUNCH(true, EPI_POOL); else if (epi == EPI_STATS) STRIP_LAUNCH(true, EPI_STATS); else STRIP_LAUNCH(true, EPI_NONE); }
     else { if (epi == EPI_POOL) STRIP_LAUNCH(false, EPI_POOL); else if (epi == EPI_STATS) STRIP_LAUNCH(false, EPI_STATS); else STRIP_LAUNCH(false, EPI_NONE); }
 #undef STRIP_LAUNCH

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
     const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
     bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, bf16* __restrict__ slice_out, long M, int C,
-    uint8_t* __restrict__ relu_bits) {
+    uint8_t* __restrict__ relu_bits, StesDet det) {
     extern __shared__ float lds[];     // [2][stat_c]
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -117,15 +117,16 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
     }
     if (stat_c > 0 && stat_sum) {
         __syncthreads();
-        if (c0 < stat_c) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { atomicAdd(&lds[c0 + i], ssum[i]); atomicAdd(&lds[stat_c + c0 + i], ssq[i]); }
-        }
+        STES_DET_LDS(det, if (c0 < stat_c) {
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) { atomicAdd(&lds[c0 + i], ssum[i]); atomicAdd(&lds[stat_c + c0 + i], ssq[i]); }
+        });
         __syncthreads();
+        det_enter(det);
         for (int i = threadIdx.x; i < stat_c; i += TPB) {
             atomicAdd(stat_sum + i, lds[i]);
             atomicAdd(stat_sumsq + i, lds[stat_c + i]);
         }
+        det_leave(det);
     }
 }
 
@@ -258,7 +259,7 @@ __global__ void se_bwd_pool_kernel(const bf16* __restrict__ c, const float* __re
 // 64 channels x 4 image lanes; one contiguous atomic per slice (the caller zeroes s_dy / s_dyr)
 __global__ __launch_bounds__(256) void se_bwd_bnsums_kernel(const float* __restrict__ S, const float* __restrict__ gate,
                                                             const float* __restrict__ dpool, float* __restrict__ s_dy,
-                                                            float* __restrict__ s_dyr, int N, int C) {
+                                                            float* __restrict__ s_dyr, int N, int C, StesDet det) {
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + cl;
@@ -273,10 +274,12 @@ __global__ __launch_bounds__(256) void se_bwd_bnsums_kernel(const float* __restr
     }
     red[0][part][cl] = a; red[1][part][cl] = b;
     __syncthreads();
+    det_enter(det);
     if (part == 0 && ch < C) {
         atomicAdd(s_dy + ch, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
         atomicAdd(s_dyr + ch, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
     }
+    det_leave(det);
 }
 
 // ---------------------------------------------------------------- sigmoid backward (squeeze-excite gate)
@@ -354,7 +357,7 @@ __device__ __forceinline__ void compute_dy(const DySrc& d, long m, int C, int c0
     }
 }
 
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_args p, FastDiv fd_group) {
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_args p, FastDiv fd_group, StesDet det) {
     extern __shared__ float lds[];     // [3][C]
     const int C = p.C, CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -382,17 +385,18 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const stes_bn_bwd_ar
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    STES_DET_LDS(det, _Pragma("unroll") for (int i = 0; i < 8; ++i) {
         atomicAdd(&lds[c0 + i], s0[i]); atomicAdd(&lds[C + c0 + i], s1[i]);
         if (r2) atomicAdd(&lds[2 * C + c0 + i], s2[i]);
-    }
+    });
     __syncthreads();
+    det_enter(det);
     for (int i = threadIdx.x; i < C; i += TPB) {
         atomicAdd(p.s_dy + i, lds[i]);
         atomicAdd(p.s_dyr1 + i, lds[C + i]);
         if (r2) atomicAdd(p.s_dyr2 + i, lds[2 * C + i]);
     }
+    det_leave(det);
 }
 
 __global__ void bn_bwd_finalize_kernel(const float* s_dy, const float* s_dyr, const float* mean, const float* invstd,
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                                                             long M, int C, FastDiv fd_hw, FastDiv fd_wi,
                                                             const bf16* __restrict__ raw1, const bf16* __restrict__ raw2,
                                                             float* __restrict__ s_dy, float* __restrict__ s_dyr1,
-                                                            float* __restrict__ s_dyr2, const uint8_t* __restrict__ x_bits) {
+                                                            float* __restrict__ s_dyr2, const uint8_t* __restrict__ x_bits, StesDet det) {
     extern __shared__ float lds[];     // [3][C] when SUMS
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -531,17 +535,18 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
     }
     if (SUMS) {
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        STES_DET_LDS(det, _Pragma("unroll") for (int k = 0; k < 8; ++k) {
             atomicAdd(&lds[c0 + k], s0[k]); atomicAdd(&lds[C + c0 + k], s1[k]);
             if (raw2) atomicAdd(&lds[2 * C + c0 + k], s2[k]);
-        }
+        });
         __syncthreads();
+        det_enter(det);
         for (int i = threadIdx.x; i < C; i += TPB) {
             atomicAdd(s_dy + i, lds[i]);
             atomicAdd(s_dyr1 + i, lds[C + i]);
             if (raw2) atomicAdd(s_dyr2 + i, lds[2 * C + i]);
         }
+        det_leave(det);
     }
 }
 
@@ -598,7 +603,8 @@ extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const
     // (measured per step over caps: 1.90 ms at 1,024 and 768 workgroups, 1.97 at the resident 1,280, 2.09 at 2,048, 2.29 at 512)
     const int grid = flat_grid(M, C / 8, cap < 1024 ? cap : 1024);
     hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
-                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C, relu_bits);
+                       shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C, relu_bits,
+                       stat_c > 0 && stat_sum ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u});
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -636,7 +642,8 @@ extern "C" int stes_se_bwd_bnsums(const float* S, const float* gate, const float
                                   void* stream) {
     STES_CHECK(S && gate && dpool && s_dy && s_dyr && N > 0 && C > 0, STES_ERR_ARG, "stes_se_bwd_bnsums: null pointer");
     int slices = N / 32; if (slices < 1) slices = 1; if (slices > 64) slices = 64;
-    hipLaunchKernelGGL(se_bwd_bnsums_kernel, dim3(stes_div_up(C, 64), slices), dim3(256), 0, S(stream), S, gate, dpool, s_dy, s_dyr, N, C);
+    hipLaunchKernelGGL(se_bwd_bnsums_kernel, dim3(stes_div_up(C, 64), slices), dim3(256), 0, S(stream), S, gate, dpool, s_dy, s_dyr, N, C,
+                       stes_det_take(stes_div_up(C, 64) * slices));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -689,7 +696,8 @@ extern "C" int stes_bn_bwd_reduce(const stes_bn_bwd_args* a, void* stream) {
     if (rc) return rc;
     STES_CHECK(a->s_dy && a->s_dyr1 && (!a->raw2 || a->s_dyr2), STES_ERR_ARG, "stes_bn_bwd_reduce: outputs");
     const int grid = flat_grid(a->M, a->C / 8, 1024);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(TPB), 3 * a->C * sizeof(float), S(stream), *a, make_fastdiv(a->group > 0 ? a->group : 1));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(TPB), 3 * a->C * sizeof(float), S(stream), *a, make_fastdiv(a->group > 0 ? a->group : 1),
+                       stes_det_take(grid));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -733,11 +741,11 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
     if (raw1)
         hipLaunchKernelGGL(block_in_grad_kernel<true>, dim3(grid), dim3(TPB), 3 * C * sizeof(float), S(stream), (const bf16*)dY, (long)ldy,
                            (const bf16*)dXf, fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C,
-                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2, x_bits);
+                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2, x_bits, stes_det_take(grid));
     else
         hipLaunchKernelGGL(block_in_grad_kernel<false>, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf,
                            fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, fhw, fwi,
-                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, x_bits);
+                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, x_bits, StesDet{nullptr, 0u, 0u});
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

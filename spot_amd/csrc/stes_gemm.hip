@@ -36,7 +36,7 @@ struct RowInfo {
 struct RowDivs { FastDiv hw, wo, gate; };
 
 template <int BN>
-__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv) {
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_kernel(const stes_gemm_args p, int m_tiles, int n_tiles, int m_slots, RowDivs dv, StesDet det) {
     constexpr int NI = BN / 32;          // 16-wide n fragments per wave (wave covers BN/2 columns)
     constexpr int BLOADS = BN / 64;      // W-tile chunk loads per thread
     // two k-steps of 32 per barrier (KB = 2 tiles per buffer): the barrier and the LDS round trip are paid once per 32 MFMAs
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_kernel(const stes
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int nt = idx % n_tiles;
     const int slot = (idx / n_tiles) * 8 + xcd;
-    if (slot >= m_slots) return;
+    if (slot >= m_slots) { det_enter(det); det_leave(det); return; }     // (deterministic mode: the turn still has to pass)
     const int n0 = nt * BN;
 
     const bf16* __restrict__ A = (const bf16*)p.A;
@@ -333,10 +333,12 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_kernel(const stes
                 if (fr == 0) { red[(wm * 2 + 0) * BN + nl] = s; red[(wm * 2 + 1) * BN + nl] = q; }
             }
         __syncthreads();
+        det_enter(det);
         for (int t = tid; t < 2 * BN; t += 256) {
             const int which = t / BN, nl = t - which * BN;
             if (n0 + nl < N) atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[which * BN + nl] + red[(2 + which) * BN + nl]);
         }
+        det_leave(det);
     }
 }
 
@@ -441,7 +443,7 @@ __device__ __forceinline__ int gsm_dest(int c, int fold) {
 // T x T output tile (T = 128 or 64) by WAVES waves arranged 2 x WAVES/2.  Eight waves on the 128 tile halve every wave's
 // accumulators and staging registers, so four waves fit a SIMD instead of two: the stage-3/4 shapes wait on memory latency.
 template <int T, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 4 : 1))) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 4 : 1))) void wgrad_kernel(const stes_wgrad_args p, int m_chunk, int t1, int t2, int m_blocks, RowDivs dv, StesDet det) {
     constexpr int WK = T == 128 ? 64 : 32;   // rows (reduction) per step and barrier: the large tile amortises the barrier
                                              // over two MFMA k-blocks; for the HBM-bound small tile that only costs residency
     constexpr int LDT = T + 16;              // padded row (elements): 32 extra bytes
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     const int n1_0 = by * T, n2_0 = bz * T;
     const long m_begin = (long)mblk * m_chunk;
     const long m_end = (m_begin + m_chunk < p.M) ? m_begin + m_chunk : p.M;
-    if (mblk >= m_blocks || m_begin >= m_end) return;
+    if (mblk >= m_blocks || m_begin >= m_end) { det_enter(det); det_leave(det); return; }
 
     const bf16* __restrict__ P = (const bf16*)p.P;
     const bf16* __restrict__ Q = (const bf16*)p.Q;
@@ -618,6 +620,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     }
 
     // D[row = n1 (fq*4 + r)][col = n2 (fr)]
+    if (do_bias) {
+        STES_DET_LDS(det, _Pragma("unroll") for (int i = 0; i < 8; ++i) atomicAdd(&bias_acc[lc * 8 + i], bsum[i]));
+        __syncthreads();
+    }
+    det_enter(det);
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -630,12 +637,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.dW + (long)n1 * p.lddw + n2d, acc[i][j][r]);
             }
         }
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&bias_acc[lc * 8 + i], bsum[i]);
-        __syncthreads();
-        if (tid < T && n1_0 + tid < p.N1) atomicAdd(p.dbias + n1_0 + tid, bias_acc[tid]);
-    }
+    if (do_bias && tid < T && n1_0 + tid < p.N1) atomicAdd(p.dbias + n1_0 + tid, bias_acc[tid]);
+    det_leave(det);
 }
 
 // ------------------------------------------------------------------ weight gradient, 320 x 320 (stage 3): strip kernel
@@ -812,7 +815,8 @@ __global__ __launch_bounds__(512) void wgrad_strip_kernel(const stes_wgrad_args 
 
 // dW += sum of the row chunks' slabs [mb][320][320]; grid (320*320/256, slab groups): a thread adds up its group's slabs for one
 // element (coalesced across the workgroup) and then adds once to dW
-__global__ __launch_bounds__(256) void wgrad_strip_fold_kernel(const float* __restrict__ ws, int mb, float* __restrict__ dW, long lddw) {
+__global__ __launch_bounds__(256) void wgrad_strip_fold_kernel(const float* __restrict__ ws, int mb, float* __restrict__ dW, long lddw,
+                                                               StesDet det) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int per = (mb + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = s0 + per < mb ? s0 + per : mb;
     constexpr int NEL = WS_N1 * 2 * WS_NQ;
@@ -823,7 +827,9 @@ __global__ __launch_bounds__(256) void wgrad_strip_fold_kernel(const float* __re
         a += (v0 + v1) + (v2 + v3);
     }
     for (; sl < s1; ++sl) a += ws[(long)sl * NEL + i];
+    det_enter(det);
     if (s1 > s0) atomicAdd(dW + (long)(i / (2 * WS_NQ)) * lddw + i % (2 * WS_NQ), a);
+    det_leave(det);
 }
 
 template <int T, int WAVES>
@@ -901,8 +907,9 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
         m_slots = slot_groups * 8;
     }
     const int grid = slot_groups * n_tiles * 8;
-    if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
-    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv);
+    const StesDet det = a->col_sum ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u};
+    if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv, det);
+    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv, det);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -934,6 +941,9 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
             dv.gate = make_fastdiv(a->q_gate ? a->gate_group : 1);
             const size_t lds = (size_t)WS_STAGES * WS_STAGE_BYTES + (size_t)(2 + WS_GMAX) * WS_NQ * sizeof(float);
             const bool slab = a->ws && a->ws_floats >= (int64_t)mb * WS_N1 * 2 * WS_NQ;
+            // (deterministic mode: without the slab workspace the strip kernel's results meet in atomics whose order nothing
+            // fixes; the tiled kernel below commits in turn)
+            const bool det_on = stes_det_take(0).ticket != nullptr;
             static const bool raised = [] {
                 bool ok = true;
                 const void* fns[4] = {reinterpret_cast<const void*>(&wgrad_strip_kernel<true, true>), reinterpret_cast<const void*>(&wgrad_strip_kernel<true, false>),
@@ -941,7 +951,7 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
                 for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
                 return ok;
             }();
-            if (raised) {
+            if (raised && (slab || !det_on)) {
                 const dim3 grid(stes_div_up(mb, 8) * 16), block(512);       // (chunk, half) -> block: see the kernel
                 hipStream_t st = (hipStream_t)stream;
                 if (pro && slab) hipLaunchKernelGGL((wgrad_strip_kernel<true, true>), grid, block, lds, st, *a, (int)chunk, dv);
@@ -950,7 +960,8 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
                 else hipLaunchKernelGGL((wgrad_strip_kernel<false, false>), grid, block, lds, st, *a, (int)chunk, dv);
                 STES_LAUNCH_CHECK();
                 if (slab) {
-                    hipLaunchKernelGGL(wgrad_strip_fold_kernel, dim3(WS_N1 * 2 * WS_NQ / 256, 8), dim3(256), 0, st, a->ws, mb, a->dW, (long)a->lddw);
+                    hipLaunchKernelGGL(wgrad_strip_fold_kernel, dim3(WS_N1 * 2 * WS_NQ / 256, 8), dim3(256), 0, st, a->ws, mb, a->dW, (long)a->lddw,
+                                       stes_det_take(WS_N1 * 2 * WS_NQ / 256 * 8));
                     STES_LAUNCH_CHECK();
                 }
                 return STES_OK;
@@ -983,10 +994,12 @@ extern "C" int stes_wgrad(const stes_wgrad_args* a, void* stream) {
     const int mb_arg = xcd_map ? mb : -mb;
     if (big) {
         const size_t lds = wgrad_lds_bytes<128, 8>();
-        hipLaunchKernelGGL((wgrad_kernel<128, 8>), dim3(grid), dim3(512), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+        hipLaunchKernelGGL((wgrad_kernel<128, 8>), dim3(grid), dim3(512), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv,
+                           stes_det_take(grid));
     } else {
         const size_t lds = wgrad_lds_bytes<64, 4>();
-        hipLaunchKernelGGL((wgrad_kernel<64, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv);
+        hipLaunchKernelGGL((wgrad_kernel<64, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, (int)chunk, t1, t2, mb_arg, dv,
+                           stes_det_take(grid));
     }
     STES_LAUNCH_CHECK();
     return STES_OK;

@@ -49,7 +49,8 @@ __device__ __forceinline__ int wg_dest(int c, int fold) {    // within-group cha
 // TAIL: the block-tail epilogue relu(e_scale*c + e_shift + residual) on the staged rows (evaluation forward of a bottleneck's
 // last 1x1 conv); its own instantiations, because the residual rows it keeps in flight cost registers every other form needs.
 template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG, bool TAIL = false>   // NB = 16*NI columns per workgroup
-__device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int row_tiles, int n_slices, int m_slots, const StreamDivs& dv) {
+__device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int row_tiles, int n_slices, int m_slots, const StreamDivs& dv,
+                                                 const StesDet& det) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(!WG || (PRO == 2 && J == 2), "the fused weight gradient rides on the BatchNorm-backward form with 32-row tiles");
     constexpr bool AFF = PRO == 1, BNB = PRO == 2;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
         }
     }
     __syncthreads();
-    if (slot >= m_slots) return;
+    if (slot >= m_slots) { det_enter(det); det_leave(det); return; }     // (deterministic mode: the turn still has to pass)
 
     const long tstride = (long)m_slots * WAVES;
     long c_tile = (long)slot * WAVES + wave;                       // scalar
@@ -420,48 +421,50 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
             gate_commit(c_tile);
         });
     }
+    if (stats) {
+        STES_DET_LDS(det, if (o_active) {
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) { atomicAdd(&red[o_chunk * 8 + e], ssum[e]); atomicAdd(&red[NB + o_chunk * 8 + e], ssq[e]); }
+        });
+        __syncthreads();
+    }
+    det_enter(det);
     if constexpr (WG) {                  // D[k][n]: lane column n = fr, rows k = 4 fq + r
-#pragma unroll
-        for (int a = 0; a < WG_PSUB; ++a)
-#pragma unroll
-            for (int b = 0; b < WG_QSUB; ++b) {
+        // (every wave holds a partial of the whole weight gradient)
+        STES_DET_WAVES(det, _Pragma("unroll") for (int a = 0; a < WG_PSUB; ++a) {
+            _Pragma("unroll") for (int b = 0; b < WG_QSUB; ++b) {
                 const int n = b * 16 + fr;
                 const int nd = n < p.wg_perm_fold ? wg_dest(n, p.wg_perm_fold) : n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(p.wg_dw + (long)(a * 16 + fq * 4 + r) * p.wg_lddw + nd, accw[a][b][r]);
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) atomicAdd(p.wg_dw + (long)(a * 16 + fq * 4 + r) * p.wg_lddw + nd, accw[a][b][r]);
             }
+        });
     }
     if (stats) {
-        if (o_active) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(&red[o_chunk * 8 + e], ssum[e]); atomicAdd(&red[NB + o_chunk * 8 + e], ssq[e]); }
-        }
-        __syncthreads();
         for (int t = tid; t < 2 * NB; t += WAVES * 64) {
             const int which = t / NB, nl = t - which * NB;
             atomicAdd((which ? p.col_sumsq : p.col_sum) + n0 + nl, red[t]);
         }
     }
+    det_leave(det);
 }
 
 template <int NI, int WAVES, int PRO, int NK, int TA, int J>
 __global__ __launch_bounds__(WAVES * 64) void gemm_stream_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
-                                                                 StreamDivs dv) {
-    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false>(p, row_tiles, n_slices, m_slots, dv);
+                                                                 StreamDivs dv, StesDet det) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false>(p, row_tiles, n_slices, m_slots, dv, det);
 }
 
 // the same with the layer's weight gradient in the same pass (see gemm_stream_body)
 template <int NI, int WAVES, int PRO, int NK, int TA, int J>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_stream_wg_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
-                                                                    StreamDivs dv) {
-    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, true>(p, row_tiles, n_slices, m_slots, dv);
+                                                                    StreamDivs dv, StesDet det) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, true>(p, row_tiles, n_slices, m_slots, dv, det);
 }
 
 // the same with the block-tail epilogue (see gemm_stream_body)
 template <int NI, int WAVES, int PRO, int NK, int TA, int J>
 __global__ __launch_bounds__(WAVES * 64) void gemm_stream_tail_kernel(const stes_gemm_args p, int row_tiles, int n_slices, int m_slots,
-                                                                      StreamDivs dv) {
-    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false, true>(p, row_tiles, n_slices, m_slots, dv);
+                                                                      StreamDivs dv, StesDet det) {
+    gemm_stream_body<NI, WAVES, PRO, NK, TA, J, false, true>(p, row_tiles, n_slices, m_slots, dv, det);
 }
 
 // Workgroups of one instantiation resident per CU at a given dynamic LDS size (queried once; the LDS size is fixed by
@@ -506,15 +509,16 @@ static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs
     const int cap = 256 * per_cu / n_slices > 8 ? 256 * per_cu / n_slices : 8;
     if (m_slots > cap) m_slots = cap;
     const int grid = stes_div_up(m_slots, 8) * n_slices * 8;
+    const StesDet det = (WG || a->col_sum) ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u};
     if constexpr (WG)
         hipLaunchKernelGGL((gemm_stream_wg_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
-                           m_slots, dv);
+                           m_slots, dv, det);
     else if constexpr (TAIL)
         hipLaunchKernelGGL((gemm_stream_tail_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
-                           m_slots, dv);
+                           m_slots, dv, det);
     else
         hipLaunchKernelGGL((gemm_stream_kernel<NI, WAVES, PRO, NK, TA, J>), dim3(grid), dim3(WAVES * 64), lds, stream, *a, row_tiles, n_slices,
-                           m_slots, dv);
+                           m_slots, dv, det);
 }
 
 template <int NI, int WAVES, int PRO>

@@ -324,7 +324,7 @@ template <int NCT, int POS>   // NCT: 16-channel tiles per group (half <= 16*NCT
 __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ dw, float* __restrict__ db, Geom gm, long n_chunks,
-                                                            FastDiv fd_nch8) {
+                                                            FastDiv fd_nch8, StesDet det) {
     // POS == 64: lane = position, one 8-byte load brings the gate gradient of both groups, the groups take turns in the
     //            Dm buffer;  POS == 32: lane = (position, group), both groups' Dm rows are live together.
     constexpr int LDD = 48;                                        // Dm row: 32 taps + 16 pad (elements)
@@ -449,27 +449,28 @@ __global__ __launch_bounds__(256) void gsm_bwd_wgrad_kernel(const float* __restr
     float* red = reinterpret_cast<float*>(&Xb[0][0]);
     for (int i = threadIdx.x; i < fold * 27; i += 256) red[i] = 0.f;
     __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NCT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
+    STES_DET_LDS(det, _Pragma("unroll") for (int g = 0; g < 2; ++g) {
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+            _Pragma("unroll") for (int j = 0; j < NCT; ++j) {
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {
                     const int tap = i * 16 + fq * 4 + r, c = j * 16 + fr;
                     if (tap < 27 && c < half) atomicAdd(&red[(g * half + c) * 27 + tap], acc[g][i][j][r]);
                 }
+            }
+        }
+    });
     __syncthreads();
+    det_enter(det);
     for (int i = threadIdx.x; i < fold * 27; i += 256) atomicAdd(dw + i, red[i]);
     if (POS == 64) {
         bsum0 = wave_sum(bsum0); bsum1 = wave_sum(bsum1);
-        if (lane == 0) { atomicAdd(db, bsum0); atomicAdd(db + 1, bsum1); }
+        STES_DET_WAVES(det, if (lane == 0) { atomicAdd(db, bsum0); atomicAdd(db + 1, bsum1); });
     } else {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) bsum0 += __shfl_xor(bsum0, o, 64);
-        if ((lane & 31) == 0) atomicAdd(db + lg, bsum0);
+        STES_DET_WAVES(det, if ((lane & 31) == 0) atomicAdd(db + lg, bsum0));
     }
+    det_leave(det);
 }
 
 // ------------------------------------------------------------------ backward: gradient at the BatchNorm3d output
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
                                                            const float* __restrict__ w3d, bf16* __restrict__ dxbn,
                                                            float* __restrict__ s_dy, float* __restrict__ s_dyr,
                                                            float* __restrict__ dw, float* __restrict__ db, float* __restrict__ ws,
-                                                           int n_rep, Geom gm, BwdTile bt) {
+                                                           int n_rep, Geom gm, BwdTile bt, StesDet det) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SA = 96;                                 // Ag row stride (bytes): 32 taps + 16 pad, an odd multiple of 32
     const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
             if (fq == 1) bsum += f[5];                      // tap 13, the centre: the position's own gate gradient (conv bias gradient)
         }
         bsum = wave_sum(bsum);
-        if (lane == 0) atomicAdd(&dbs[g], bsum);
+        STES_DET_LDS(det, if (lane == 0) atomicAdd(&dbs[g], bsum));
         __syncthreads();
         // ---- (b) conv weight gradient: a wave owns whole output tiles D[16 channels][16 taps] and walks every 32-position
         // step itself, so the result needs no reduction between waves (LDS float atomics cost ~2 cycles per lane)
@@ -1051,6 +1052,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
     // one of its n_rep replicas (every workgroup adding to the same few KiB serialises in the memory-side atomic units) and
     // gsm_bwd_fold_kernel adds the replicas up; without one they go to the results directly.
     const int nws = fold * 27 + 2 * fold + 2;
+    det_enter(det);
     if (ws) {
         float* rep = ws + (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % n_rep * nws;
         for (int i = tid; i < nws; i += 256) atomicAdd(rep + i, red[i]);
@@ -1059,6 +1061,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
         for (int i = tid; i < fold; i += 256) { atomicAdd(s_dy + i, sums[i]); atomicAdd(s_dyr + i, sums[fold + i]); }
         if (tid < 2) atomicAdd(db + tid, dbs[tid]);
     }
+    det_leave(det);
 }
 
 // adds the workspace replicas of gsm_bwd_conv_kernel to the results and leaves the workspace zero for the next call
@@ -1086,7 +1089,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_fold_kernel(float* __restrict__ w
 
 // ------------------------------------------------------------------ column statistics / slice copy of a strided tensor
 __global__ __launch_bounds__(256) void col_stats_kernel(const bf16* __restrict__ X, long ldx, int ncols, long M, float* sum, float* sumsq,
-                                                        bf16* __restrict__ copy) {
+                                                        bf16* __restrict__ copy, StesDet det) {
     extern __shared__ float lds[];
     for (int i = threadIdx.x; i < 2 * ncols; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
@@ -1099,9 +1102,11 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const bf16* __restrict__
         const float v = (float)xv; a += v; b += v * v;
     }
     if (sum) {
-        atomicAdd(&lds[c], a); atomicAdd(&lds[ncols + c], b);
+        STES_DET_LDS(det, atomicAdd(&lds[c], a); atomicAdd(&lds[ncols + c], b));
         __syncthreads();
+        det_enter(det);
         for (int i = threadIdx.x; i < ncols; i += blockDim.x) { atomicAdd(sum + i, lds[i]); atomicAdd(sumsq + i, lds[ncols + i]); }
+        det_leave(det);
     }
 }
 
@@ -1279,7 +1284,7 @@ extern "C" int stes_gsm_bwd_wgrad(const float* dpre, const uint16_t* Xc, const f
         }();                                                                                                                       \
         long gx = (n_chunks + 31) / 32;                                                                                            \
         if (gx > resident) gx = resident;                                                                                          \
-        hipLaunchKernelGGL((gsm_bwd_wgrad_kernel<N, P>), dim3((int)gx), dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks, fd_nch8); \
+        hipLaunchKernelGGL((gsm_bwd_wgrad_kernel<N, P>), dim3((int)gx), dim3(256), 0, S(stream), dpre, (const bf16*)Xc, scale, shift, dw, db, gm, n_chunks, fd_nch8, stes_det_take((unsigned)gx)); \
     } while (0)
     switch (nct) {
         case 1: LAUNCH_WG(1, 64); break;
@@ -1342,7 +1347,7 @@ extern "C" int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t
     STES_CHECK(X && ncols > 0 && ncols <= ldx && M > 0 && (sum == nullptr) == (sumsq == nullptr) && (sum || copy), STES_ERR_ARG, "stes_col_stats: bad argument");
     const int blocks = flat_blocks(M * ncols, 256, ncols);
     hipLaunchKernelGGL(col_stats_kernel, dim3(blocks), dim3(256), (size_t)(2 * ncols) * sizeof(float), S(stream), (const bf16*)X, (long)ldx,
-                       ncols, (long)M, sum, sumsq, (bf16*)copy);
+                       ncols, (long)M, sum, sumsq, (bf16*)copy, sum ? stes_det_take(blocks) : StesDet{nullptr, 0u, 0u});
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -1414,7 +1419,7 @@ extern "C" int stes_gsm_bwd_conv(const float* dpre, const uint16_t* Xc, const fl
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;     \
         STES_CHECK(big_lds || lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: cannot raise the dynamic LDS limit");    \
         hipLaunchKernelGGL((gsm_bwd_conv_kernel<N>), grid, dim3(256), lds, S(stream), dpre, (const bf16*)Xc, scale, shift, w3d,   \
-                           (bf16*)dxbn, s_dy, s_dyr, dw, db, ws, STES_GSM_WS_REPLICAS, gm, bt);                                    \
+                           (bf16*)dxbn, s_dy, s_dyr, dw, db, ws, STES_GSM_WS_REPLICAS, gm, bt, stes_det_take(grid.x * grid.y * grid.z)); \
     } while (0)
     switch (nct) {
         case 1: BWD_CASE(1); break;

@@ -32,6 +32,12 @@ F32 = torch.float32
 OVERLAP = os.environ.get("STES_SERIAL", "0") != "1"
 
 
+def overlap():
+    """Side-stream execution is on (never in the library's deterministic mode, which fixes the order of every float
+    accumulation and therefore wants all launches on one stream, in program order)."""
+    return OVERLAP and lib.deterministic_ticket() is None
+
+
 def _rup(x, m):
     return (x + m - 1) // m * m
 
@@ -242,7 +248,7 @@ class Block:
             main.wait_event(e.side_done[par])
 
         def side(fn):
-            if not OVERLAP:
+            if not overlap():
                 return fn()
             e.side.wait_stream(main)
             with torch.cuda.stream(e.side):
@@ -775,7 +781,7 @@ class Engine:
         if self.loc is not None:
             # the location MLP does not depend on the temporal head, and the recurrence (a hundred small dependent launches)
             # leaves most of the GPU idle: the MLP runs beside it on the side stream
-            loc_on_side = OVERLAP and self.head_kind == "gru"
+            loc_on_side = overlap() and self.head_kind == "gru"
             if loc_on_side:
                 self.side.wait_stream(main)
             with torch.cuda.stream(self.side) if loc_on_side else contextlib.nullcontext():
@@ -852,7 +858,7 @@ class Engine:
             return d
         # the location MLP's backward beside the recurrence's (see _heads_forward)
         main0 = torch.cuda.current_stream()
-        loc_on_side = OVERLAP and has_loc and self.head_kind == "gru"
+        loc_on_side = overlap() and has_loc and self.head_kind == "gru"
         if loc_on_side:
             self.side.wait_stream(main0)
             with torch.cuda.stream(self.side):

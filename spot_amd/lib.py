@@ -121,7 +121,7 @@ _SIGS = {
     "stes_cast_bf16_multi": [_P, _I32, _I32, _P],
 }
 EXPORTS = ["stes_version", "stes_last_error", "stes_gsm_bwd_conv_ws_floats", "stes_gru_ws_floats", "stes_wgrad_ws_floats",
-           "stes_augment_ws_floats", "stes_gru_set_spin_limit", "stes_gru_noalloc_prepare"] + list(_SIGS)
+           "stes_augment_ws_floats", "stes_gru_set_spin_limit", "stes_gru_noalloc_prepare", "stes_set_deterministic"] + list(_SIGS)
 
 
 def lib():
@@ -145,6 +145,8 @@ def lib():
         L.stes_gru_set_spin_limit.restype = C.c_int
         L.stes_gru_noalloc_prepare.argtypes = []
         L.stes_gru_noalloc_prepare.restype = C.c_int
+        L.stes_set_deterministic.argtypes = [_P, _P]
+        L.stes_set_deterministic.restype = C.c_int
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.argtypes = sig
@@ -154,6 +156,28 @@ def lib():
 
 
 ERR_UNSUPPORTED = -3        # STES_ERR_UNSUPPORTED in include/stes.h
+
+_det_ticket = None
+
+
+def set_deterministic(on: bool):
+    """The library's deterministic mode (stes_set_deterministic in include/stes.h): every cross-workgroup float sum is
+    committed in a fixed order, so two runs of the same work give the same bits.  A test mode: slower, one stream."""
+    global _det_ticket
+    torch.cuda.synchronize()
+    if on:
+        t = torch.zeros(64, dtype=torch.int32, device="cuda")
+        check(lib().stes_set_deterministic(t.data_ptr(), stream()), "stes_set_deterministic")
+        _det_ticket = t
+    else:
+        check(lib().stes_set_deterministic(None, stream()), "stes_set_deterministic")
+        _det_ticket = None
+    torch.cuda.synchronize()
+
+
+def deterministic_ticket():
+    """The ticket tensor while the deterministic mode is on (word 1 != 0: a workgroup's wait for its turn ran out), else None."""
+    return _det_ticket
 
 
 def check(rc: int, what: str):

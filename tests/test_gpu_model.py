@@ -64,9 +64,29 @@ def test_eval_forward_vs_reference_golden(golden):
     np.testing.assert_allclose(loc, oloc, atol=2e-2)
 
 
-@pytest.mark.parametrize("arch,tarch,tag,clip_len", [("rny008_gsm", "gru", "full_rny008_gsm_gru", 4), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru", 4),
-                                                     ("rny008_gsm", "gru", "full_rny008_gsm_gru_128", 8)])
-def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag, clip_len):
+@pytest.fixture
+def deterministic_mode(request):
+    """Switches the library's deterministic mode on for tests parametrised with det=True (and always off again)."""
+    from spot_amd import lib
+    on = bool(getattr(request, "param", False))
+    if on:
+        lib.set_deterministic(True)
+    try:
+        yield on
+        if on:
+            assert int(lib.deterministic_ticket()[1]) == 0, "a workgroup's wait for its turn ran out: the order was not kept"
+    finally:
+        if on:
+            lib.set_deterministic(False)
+
+
+@pytest.mark.parametrize("arch,tarch,tag,clip_len,deterministic_mode", [
+    ("rny008_gsm", "gru", "full_rny008_gsm_gru", 4, False), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru", 4, False),
+    ("rny008_gsm", "gru", "full_rny008_gsm_gru_128", 8, False),
+    # the same criteria with every float accumulation in a fixed order (one reproducible realisation instead of a draw)
+    ("rny008_gsm", "gru", "full_rny008_gsm_gru_128", 8, True), ("rny008_tsm", "mingru", "full_rny008_tsm_mingru", 4, True)],
+    indirect=["deterministic_mode"])
+def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag, clip_len, deterministic_mode):
     """Training-mode outputs, loss and every parameter gradient against the reference's own fp32 run (golden) -- for the
     plain temporal shift this includes the autograd consequences of the reference's in-place shift (model/shift.py:55-78):
     unshifted shortcut gradient, ReLU mask taken from the shifted tensor.  The 128x128 case (16 frames, 4x4 final map) is
@@ -182,6 +202,60 @@ def test_train_forward_backward_vs_reference_and_oracle(golden, arch, tarch, tag
     for n, b in impl.named_buffers():
         if "buf." + n in z.files:
             np.testing.assert_allclose(b.cpu().numpy(), z["buf." + n], rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("arch,tarch", [("rny008_gsm", "gru"), ("rny008_tsm", "mingru")])
+def test_deterministic_mode_gives_bit_identical_steps(arch, tarch):
+    """Run-to-run differences of a training step come from the order of fp32 atomics (BatchNorm sums, BatchNorm-backward
+    sums, weight gradients) and from nothing else: with that order fixed (the library's deterministic mode) two runs of the
+    same step give the same bits in every gradient, every BatchNorm buffer and the loss.  A race between kernels, a read of
+    uninitialised scratch memory or a missing stream dependency would survive the mode and fail this test.  Without the
+    mode the same two runs differ (which shows that the test can tell)."""
+    from spot_amd import lib
+    _, m = build(arch, tarch, seed=6)
+    eng = m._model.engine
+    if tarch == "gru":
+        m._model._pred_fine._dropout.p = 0.0
+        eng.drop_p = 0.0
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 4, 3, 64, 64, generator=g).cuda()
+    label = torch.randint(0, 7, (2, 4), generator=g); label[0, 0] = 0; label[1, 1] = 3
+    label, xy = label.cuda(), torch.rand(2, 4, 2, generator=g).cuda()
+    sd = {k: v.clone() for k, v in m._model.state_dict().items()}
+
+    def run():
+        m._model.load_state_dict(sd)
+        out = m.train_step(x, label, xy, lr=0.0, optimizer_step=False)
+        torch.cuda.synchronize()
+        bufs = torch.cat([b.detach().float().flatten() for _, b in m._model.named_buffers()])
+        return eng.flat_grad.clone(), bufs.clone(), out[:3].clone()
+
+    bits = lambda t: t.contiguous().view(torch.int32)
+    lib.set_deterministic(True)
+    try:
+        a, b = run(), run()
+        assert int(lib.deterministic_ticket()[1]) == 0
+    finally:
+        lib.set_deterministic(False)
+    assert bool(torch.isfinite(a[0]).all()) and float(a[0].abs().max()) > 0
+    for u, v, what in zip(a, b, ("gradients", "BatchNorm buffers", "loss")):
+        same = torch.equal(bits(u), bits(v))
+        if not same:
+            bad = (bits(u) != bits(v)).nonzero().flatten()
+            names = []
+            if what == "gradients":
+                for name, p in m._model.named_parameters():
+                    o, n, _ = eng._goff[id(p)]
+                    if bool(((bad >= o) & (bad < o + n)).any()):
+                        names.append(name)
+            raise AssertionError("%s differ between two deterministic runs in %d elements: %s" % (what, bad.numel(), names[:12]))
+    # and the deterministic realisation is one of the ordinary ones: same loss, gradients as close as two ordinary runs are
+    c, d = run(), run()
+    cos = lambda p, q: float((p.double() * q.double()).sum() / (p.double().norm() * q.double().norm()))
+    print("gradient cosine: ordinary/ordinary %.4f, deterministic/ordinary %.4f" % (cos(c[0], d[0]), cos(a[0], c[0])))
+    assert not torch.equal(bits(c[0]), bits(d[0])), "two ordinary runs gave the same bits: the test cannot tell the modes apart"
+    assert cos(a[0], c[0]) > min(0.9, cos(c[0], d[0]) - 0.05)
+    assert abs(float(a[2][0] - c[2][0])) < 2e-2 * abs(float(c[2][0]))
 
 
 def test_fused_train_step_matches_reference_step_semantics():
