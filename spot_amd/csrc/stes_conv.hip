@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
     unsigned char* ring = smem;
     const unsigned ring_lds = (unsigned)(size_t)smem; // LDS byte address of the window
     unsigned char* stage = smem + NR * ROWB;          // [RS*Wd][128 B]
-    float* red = reinterpret_cast<float*>(stage + RS * Wd * 128);   // [2][64]
+    // (at least 1 KiB of staging: the per-image pooled sums of the four waves pass through it, and a 2 x 2 map stages only 512 bytes)
+    float* red = reinterpret_cast<float*>(stage + (RS * Wd * 128 < 1024 ? 1024 : RS * Wd * 128));   // [2][64]
 
     bf16x8 wf[5];
 #pragma unroll
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3g_rows_kernel(const bf16* __res
         const int r = i >> 4, side = (i >> 3) & 1, ch = i & 7;
         *reinterpret_cast<bf16x8*>(ring + r * ROWB + (side ? (Ws + 1) * PSB : 0) + ch * 16) = zero8();
     }
-    if (tid < 128) red[tid] = 0.f;
     if constexpr (POOL) {                                // red holds the pooling affine instead of statistics
-        if (tid < 64) { red[tid] = pool_scale[cb * 64 + tid]; red[64 + tid] = pool_shift[cb * 64 + tid]; }
-    }
+        // (each word written by one thread only: zeroing all of red first would race with these stores across waves)
+        if (tid < 128) red[tid] = tid < 64 ? pool_scale[cb * 64 + tid] : pool_shift[cb * 64 + tid - 64];
+    } else if (tid < 128) red[tid] = 0.f;
 
     const bf16* img = nullptr;                           // this image, this channel block (uniform)
     bf16x8 regs[CONV_MAXI];
@@ -935,7 +936,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
         const int st = mode == 0 ? stride : 1;
         auto lds_of = [&](int rs) {
             const int nr = st == 1 ? rs + 2 : 2 * rs + 1;
-            return (size_t)nr * (rg.Ws + 2) * PSB + (size_t)rs * rg.Wd * 128 + 128 * sizeof(float) + CONV_NF * CONV_NG * 16 * sizeof(int);
+            const size_t staging = (size_t)rs * rg.Wd * 128 < 1024 ? 1024 : (size_t)rs * rg.Wd * 128;    // see the kernel
+            return (size_t)nr * (rg.Ws + 2) * PSB + staging + 128 * sizeof(float) + CONV_NF * CONV_NG * 16 * sizeof(int);
         };
         int cap = CONV_MAXP / rg.Wd; if (cap < 1) cap = 1; if (cap > rg.Hd) cap = rg.Hd;
         // more than one step per image: the rows carried from step to step must fit their registers

@@ -43,12 +43,18 @@ def close(a, b, rtol=1e-2, atol=1e-2):
     torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("stride,H,W,C", [(1, 14, 14, 64), (2, 16, 12, 64), (1, 7, 7, 128), (2, 28, 28, 128), (2, 9, 7, 64), (1, 28, 28, 128),
-                                             (2, 56, 56, 64), (1, 30, 50, 64), (2, 25, 13, 320), (1, 13, 25, 192), (2, 40, 199, 64)])
-def test_conv3x3g(stride, H, W, C):
+@pytest.mark.parametrize("stride,H,W,C,N", [(1, 14, 14, 64, 3), (2, 16, 12, 64, 3), (1, 7, 7, 128, 3), (2, 28, 28, 128, 3), (2, 9, 7, 64, 3),
+                                               (1, 28, 28, 128, 3), (2, 56, 56, 64, 3), (1, 30, 50, 64, 3), (2, 25, 13, 320, 3), (1, 13, 25, 192, 3),
+                                               (2, 40, 199, 64, 3),
+                                               # many images: a workgroup of the column-strip kernel owns a range of rows that starts
+                                               # and ends inside images (7 rows x 1,500 images over about a thousand workgroups)
+                                               (1, 7, 7, 64, 1500), (1, 4, 4, 320, 900), (1, 14, 9, 64, 333), (1, 2, 2, 128, 2000),
+                                               # several images per workgroup of the LDS-window kernel on maps of fewer than 8 output pixels
+                                               # (the pooled sums of the four waves need more staging space than such a map's pixels)
+                                               (2, 4, 4, 128, 600), (2, 3, 3, 64, 1100), (2, 4, 6, 64, 1100)])
+def test_conv3x3g(stride, H, W, C, N):
     from spot_amd import lib
     g = torch.Generator().manual_seed(3)
-    N = 3
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     x = bfr(N, C, H, W, g=g)
     w = torch.randn(C, 16, 3, 3, generator=g) * 0.1
@@ -463,7 +469,9 @@ def _gsm_run(z, mode, fused=False):
 
 
 @pytest.mark.parametrize("B,T,H,W,fold", [(2, 3, 9, 20, 8), (2, 3, 9, 30, 8), (1, 5, 13, 50, 16), (1, 3, 30, 30, 32), (1, 9, 14, 14, 80),
-                                          (1, 5, 7, 7, 192), (1, 11, 40, 36, 16), (1, 4, 25, 13, 32)])
+                                          (1, 5, 7, 7, 192), (1, 11, 40, 36, 16), (1, 4, 25, 13, 32),
+                                          # full-length clips on the small maps of a 64 x 64 crop
+                                          (1, 64, 16, 16, 16), (1, 64, 4, 4, 80), (2, 64, 2, 2, 192), (1, 64, 1, 1, 192)])
 def test_gsm_gate_tiling(B, T, H, W, fold):
     """The gate kernel's row tiles, frame segments, ragged strips and both thread mappings against conv3d
     (reference model/shift.py:108-113) on the same bf16-rounded operands."""
