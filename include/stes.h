@@ -246,6 +246,20 @@ int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Cin, int H, i
 int stes_im2col_stem_u8(const uint8_t* x, uint16_t* patches, const float* mean, const float* std, int B, int T, int T_valid,
                         int Cin, int H, int W, void* stream);
 
+/* The stem convolution in one pass, without the round trip of its patches through memory (the 3x3 stride-2 convolution of
+ * timm's RegNet stem as the reference builds it, model/shift.py / model/modules.py via timm.create_model at
+ * train_e2e_spatial.py:230-300; the normalisation of uint8 frames follows dataset/frame.py:29,:124).
+ * x: [B*T][Cin][H][W] fp32 (x_is_u8 == 0, T_valid == T), or [B*T_valid][Cin][H][W] uint8 laid out as B clips of T frames
+ * whose missing frames are zero after normalisation, with HOST mean/std of Cin floats.  w_bf: [32][32] bf16, row = output
+ * channel, column k = ci*9 + kh*3 + kw (zero from Cin*9 up).
+ * Training form (e_scale == NULL): out = the raw output [B*T*Ho*Wo][32], patches (required) = what stes_im2col_stem gives,
+ * col_sum/col_sumsq (optional, 32 floats each) += column statistics of the rounded output.
+ * Evaluation form: out = relu(e_scale * c + e_shift); e_slice (optional) = its first e_slice_n (multiple of 8) channels as
+ * [B*T*Ho*Wo][e_slice_n]; patches is not written. */
+int stes_stem_conv(const void* x, int x_is_u8, const float* mean, const float* stdv, const uint16_t* w_bf, uint16_t* patches,
+                   uint16_t* out, float* col_sum, float* col_sumsq, const float* e_scale, const float* e_shift,
+                   uint16_t* e_slice, int e_slice_n, int B, int T, int T_valid, int Cin, int H, int W, void* stream);
+
 /* ---------------------------------------------------- clip augmentation ----
  * The training loader's random augmentation (reference dataset/frame.py:78-140, applied per clip with one set of random
  * parameters, :296-323) on decoded uint8 frames x [n_clips*T][3][Hs][Ws]: ONE resampling through a per-clip homography (the

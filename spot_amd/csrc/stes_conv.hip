@@ -903,6 +903,187 @@ __global__ __launch_bounds__(256) void im2col_stem_u8_kernel(const uint8_t* __re
     }
 }
 
+// ------------------------------------------------------------------ stem convolution in one pass
+// The stem's 3x3 stride-2 convolution (3 -> 32 channels) without the round trip of its patches through memory.  A unit of
+// work is STEM_R output rows of one image: the workgroup stages the 2*STEM_R + 1 input rows they need (three channel planes,
+// bf16, data column 0 at element 4 of a row so that four columns are one aligned 8-byte LDS write; elements 3 and 4 + W are
+// the zero halo) with every load of the unit issued before the first is waited for, and each wave then builds, for 16 output
+// pixels at a time, the B operand of a 16x16x32 MFMA straight from there (lane (pixel, q) gathers taps 8q..8q+7 of its pixel:
+// k = ci*9 + kh*3 + kw, zero from 27 up) against the two 16-channel halves of the weight matrix as A operands.  The result
+// D[channel 4q + i][pixel] gives every lane four consecutive channels of its pixel twice: two 8-byte stores, no transposition.
+// Workgroups walk over units with a grid stride and commit their column statistics once at the end (one atomic per channel and
+// workgroup: the 64 sums live in two cache lines, so their number decides the cost).
+// Training: the raw output, its column statistics and -- because the weight gradient reads them -- the patches, written from
+// the operand registers.  Evaluation: relu(scale * c + shift) instead of the raw output and, on request, the first channels
+// of every pixel as the next layer's compact gated-shift slice; nothing else is written.
+// U8: x holds decoded uint8 frames and the normalisation (u / 255 - mean) / std of im2col_stem_u8_kernel is applied when the
+// rows are staged; clips of Tv frames are laid out as clips of T frames, the missing ones zero.
+// VEC: W is a multiple of 4 and x is aligned for four-column loads.
+constexpr int STEM_R = 4;
+constexpr int STEM_ROWS = 2 * STEM_R + 1;
+constexpr int STEM_LD = 6;                                                   // four-column loads in flight per thread
+
+struct StemGeom { int T, Tv, Cin, H, W, Ho, Wo, groups, LW; long units; };
+
+template <bool U8, bool EVAL, bool VEC>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__ xin, StemNorm nm, const bf16* __restrict__ wbf,
+                                                        bf16* __restrict__ patches, bf16* __restrict__ out, float* col_sum,
+                                                        float* col_sumsq, const float* __restrict__ e_scale,
+                                                        const float* __restrict__ e_shift, bf16* __restrict__ e_slice, int e_slice_n,
+                                                        StemGeom gm, StesDet det) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stem_smem[];
+    bf16* rows = reinterpret_cast<bf16*>(stem_smem);                        // [3 channels][STEM_ROWS][LW]
+    const int LW = gm.LW, W = gm.W, H = gm.H, Wo = gm.Wo, Ho = gm.Ho, Cin = gm.Cin;
+    float* red = reinterpret_cast<float*>(rows + 3 * STEM_ROWS * LW);        // [2][4 waves][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int nq = (W + 3) >> 2, quads = 3 * STEM_ROWS * nq;                 // four-column pieces of a row, of a unit
+    // this lane's eight taps, as offsets from the staged element of (input row 2*orow - 1 of the unit's first, column 2*wo - 1)
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        const int ci = k / 9, kh = (k - ci * 9) / 3, kw = k - ci * 9 - kh * 3;
+        toff[j] = k < 27 ? (ci * STEM_ROWS + kh) * LW + kw + 3 : -1;
+    }
+    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wbf + (long)p * 32 + q * 8);            // A operand: row = output channel
+    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wbf + (long)(16 + p) * 32 + q * 8);
+    float es[8], eb[8];
+    if (EVAL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            es[i] = e_scale[4 * q + i]; es[4 + i] = e_scale[16 + 4 * q + i];
+            eb[i] = e_shift[4 * q + i]; eb[4 + i] = e_shift[16 + 4 * q + i];
+        }
+    }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
+    // zero halo columns (never written by the staging below)
+    for (int i = tid; i < 3 * STEM_ROWS * 2; i += 256) rows[(i >> 1) * LW + ((i & 1) ? 4 + W : 3)] = (bf16)0.f;
+
+    for (long unit = blockIdx.x; unit < gm.units; unit += gridDim.x) {
+        const int n = (int)(unit / gm.groups), grp = (int)(unit - (long)n * gm.groups);   // image (of B * T), group of output rows
+        const int ho0 = STEM_R * grp;
+        long src_img = n;
+        bool live = true;
+        if (U8) { const int b = n / gm.T, t = n - b * gm.T; live = t < gm.Tv; src_img = (long)b * gm.Tv + t; }
+        // ---- stage input rows 2*ho0 - 1 .. 2*ho0 + 2*STEM_R - 1 of the three planes
+        for (int e0 = 0; e0 < quads; e0 += 256 * STEM_LD) {
+            float4 v[STEM_LD];
+            int at[STEM_LD];
+#pragma unroll
+            for (int u = 0; u < STEM_LD; ++u) {
+                const int e = e0 + u * 256 + tid;
+                const int rp = e / nq, c4 = e - rp * nq;                     // row-plane (ci * STEM_ROWS + row), piece
+                const int ci = rp / STEM_ROWS, r = 2 * ho0 - 1 + (rp - ci * STEM_ROWS);
+                at[u] = e < quads ? rp * LW + 4 + 4 * c4 : -1;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < quads && live && ci < Cin && r >= 0 && r < H) {
+                    const long o = ((src_img * Cin + ci) * H + r) * (long)W + 4 * c4;
+                    if (U8) {
+                        const float mu = ci == 0 ? nm.mean[0] : ci == 1 ? nm.mean[1] : nm.mean[2];
+                        const float sd = ci == 0 ? nm.stdv[0] : ci == 1 ? nm.stdv[1] : nm.stdv[2];
+                        const uint8_t* xs = reinterpret_cast<const uint8_t*>(xin) + o;
+                        unsigned b4 = 0;
+                        if (VEC) b4 = *reinterpret_cast<const unsigned*>(xs);
+                        else {
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) if (4 * c4 + z < W) b4 |= (unsigned)xs[z] << (8 * z);
+                        }
+                        v[u].x = ((float)(b4 & 255u) / 255.0f - mu) / sd;         v[u].y = ((float)((b4 >> 8) & 255u) / 255.0f - mu) / sd;
+                        v[u].z = ((float)((b4 >> 16) & 255u) / 255.0f - mu) / sd; v[u].w = ((float)(b4 >> 24) / 255.0f - mu) / sd;
+                    } else {
+                        const float* xs = reinterpret_cast<const float*>(xin) + o;
+                        if (VEC) v[u] = *reinterpret_cast<const float4*>(xs);
+                        else {
+                            v[u].x = xs[0];
+                            if (4 * c4 + 1 < W) v[u].y = xs[1];
+                            if (4 * c4 + 2 < W) v[u].z = xs[2];
+                            if (4 * c4 + 3 < W) v[u].w = xs[3];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < STEM_LD; ++u) {
+                if (at[u] < 0) continue;
+                bf16x4 h;
+                h[0] = (bf16)v[u].x; h[1] = (bf16)v[u].y; h[2] = (bf16)v[u].z; h[3] = (bf16)v[u].w;
+                if (VEC) *reinterpret_cast<bf16x4*>(rows + at[u]) = h;
+                else {
+                    const int c0 = at[u] - (at[u] / LW) * LW - 4;                  // first column of the piece
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) if (c0 + z < W) rows[at[u] + z] = h[z];   // (column W is the zero halo)
+                }
+            }
+        }
+        __syncthreads();
+        const int nrow = min(STEM_R, Ho - ho0);
+        const int npx = nrow * Wo;                                           // output pixels of the unit, row-major over its rows
+        const long pix0 = ((long)n * Ho + ho0) * Wo;
+        for (int t0 = wave * 16; t0 < npx; t0 += 64) {
+            const bool ok = t0 + p < npx;
+            const int px = ok ? t0 + p : npx - 1;
+            const int orow = (px >= Wo) + (px >= 2 * Wo) + (px >= 3 * Wo);
+            static_assert(STEM_R == 4, "the row of a pixel is found by three comparisons");
+            const int wo = px - orow * Wo;
+            const bf16* base = rows + 2 * orow * LW + 2 * wo;
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16 t = base[toff[j] >= 0 ? toff[j] : 3];
+                a[j] = toff[j] >= 0 ? t : (bf16)0.f;
+            }
+            if (!EVAL && ok) *reinterpret_cast<bf16x8*>(patches + (pix0 + px) * 32 + q * 8) = a;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a, z, 0, 0, 0);       // D[channel 4q + i][pixel p]
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a, z, 0, 0, 0);
+            bf16x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v0 = d0[i], v1 = d1[i];
+                if (EVAL) { v0 = fmaxf(v0 * es[i] + eb[i], 0.f); v1 = fmaxf(v1 * es[4 + i] + eb[4 + i], 0.f); }
+                o0[i] = (bf16)v0; o1[i] = (bf16)v1;
+                if (!EVAL) {
+                    const float f0 = ok ? (float)o0[i] : 0.f, f1 = ok ? (float)o1[i] : 0.f;
+                    ssum[i] += f0; ssq[i] += f0 * f0; ssum[4 + i] += f1; ssq[4 + i] += f1 * f1;
+                }
+            }
+            if (ok) {
+                bf16* orow_p = out + (pix0 + px) * 32;
+                *reinterpret_cast<bf16x4*>(orow_p + 4 * q) = o0;
+                *reinterpret_cast<bf16x4*>(orow_p + 16 + 4 * q) = o1;
+                if (EVAL && e_slice) {
+                    if (4 * q < e_slice_n) *reinterpret_cast<bf16x4*>(e_slice + (pix0 + px) * e_slice_n + 4 * q) = o0;
+                    if (16 + 4 * q < e_slice_n) *reinterpret_cast<bf16x4*>(e_slice + (pix0 + px) * e_slice_n + 16 + 4 * q) = o1;
+                }
+            }
+        }
+        __syncthreads();                                                     // the rows are overwritten by the next unit
+    }
+    if (!EVAL && col_sum) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a = ssum[i], b = ssq[i];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+            if (p == 0) {
+                const int c = (i < 4 ? 0 : 16) + 4 * q + (i & 3);
+                red[wave * 32 + c] = a; red[128 + wave * 32 + c] = b;
+            }
+        }
+        __syncthreads();
+        det_enter(det);
+        if (tid < 64) {
+            const int which = tid >> 5, c = tid & 31;
+            const float* r = red + which * 128 + c;
+            atomicAdd((which ? col_sumsq : col_sum) + c, (r[0] + r[32]) + (r[64] + r[96]));
+        }
+        det_leave(det);
+    }
+}
+
 }  // namespace
 
 #define S(s) ((hipStream_t)(s))
@@ -1134,6 +1315,62 @@ extern "C" int stes_im2col_stem(const float* x, uint16_t* patches, int N, int Ci
     long blocks = ((long)N * Ho * Wo + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(im2col_stem_kernel, dim3((int)blocks), dim3(256), 0, S(stream), x, (bf16*)patches, N, Cin, H, W, Ho, Wo);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+// Workgroups of a stem kernel that are resident at once on the whole GPU (its grid: the units are walked with a grid stride).
+template <class K>
+static long stem_resident(K kernel, size_t lds) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (long)per_cu * (cus > 0 ? cus : 256);
+}
+
+// x: [N][Cin][H][W] fp32 (x_is_u8 == 0), or [B*T_valid][Cin][H][W] uint8 laid out as B clips of T frames (the missing frames
+// zero after normalisation) with HOST mean/std of Cin floats.  w_bf: the stem weight [32][32] bf16, row = output channel,
+// column k = ci*9 + kh*3 + kw.  Training form (e_scale == NULL): out = raw conv output [N*Ho*Wo][32], patches likewise
+// (required), column statistics added to col_sum / col_sumsq when given.  Evaluation form: out = relu(e_scale*c + e_shift),
+// e_slice (optional) = its first e_slice_n channels as [N*Ho*Wo][e_slice_n].
+extern "C" int stes_stem_conv(const void* x, int x_is_u8, const float* mean, const float* stdv, const uint16_t* w_bf, uint16_t* patches,
+                              uint16_t* out, float* col_sum, float* col_sumsq, const float* e_scale, const float* e_shift,
+                              uint16_t* e_slice, int e_slice_n, int B, int T, int T_valid, int Cin, int H, int W, void* stream) {
+    STES_CHECK(x && w_bf && out && B > 0 && T > 0 && T_valid > 0 && T_valid <= T && Cin >= 1 && Cin <= 3 && H > 0 && W > 0, STES_ERR_ARG,
+               "stes_stem_conv: bad argument");
+    STES_CHECK(x_is_u8 || T_valid == T, STES_ERR_ARG, "stes_stem_conv: only uint8 clips are padded in time");
+    STES_CHECK((e_scale == nullptr) == (e_shift == nullptr) && (col_sum == nullptr) == (col_sumsq == nullptr), STES_ERR_ARG, "stes_stem_conv: paired pointers");
+    const bool eval = e_scale != nullptr;
+    STES_CHECK(eval || patches, STES_ERR_ARG, "stes_stem_conv: the training form writes the patches");
+    STES_CHECK(!eval || (!col_sum && (!e_slice || (e_slice_n > 0 && e_slice_n <= 32 && e_slice_n % 4 == 0))), STES_ERR_ARG, "stes_stem_conv: evaluation form arguments");
+    StemNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        nm.mean[c] = (x_is_u8 && c < Cin) ? mean[c] : 0.f;
+        nm.stdv[c] = (x_is_u8 && c < Cin) ? stdv[c] : 1.f;
+        STES_CHECK(nm.stdv[c] > 0.f, STES_ERR_ARG, "stes_stem_conv: std must be positive");
+    }
+    STES_CHECK(!x_is_u8 || (mean && stdv), STES_ERR_ARG, "stes_stem_conv: uint8 input needs mean and std");
+    StemGeom gm;
+    gm.T = T; gm.Tv = T_valid; gm.Cin = Cin; gm.H = H; gm.W = W;
+    gm.Ho = (H - 1) / 2 + 1; gm.Wo = (W - 1) / 2 + 1; gm.groups = (gm.Ho + STEM_R - 1) / STEM_R;
+    gm.LW = (W + 8 + 3) & ~3;
+    gm.units = (long)B * T * gm.groups;
+    STES_CHECK((long)B * T * gm.Ho * gm.Wo < (1L << 31) / 32, STES_ERR_UNSUPPORTED, "stes_stem_conv: too many pixels");
+    const size_t lds = (size_t)3 * STEM_ROWS * gm.LW * 2 + 2 * 4 * 32 * sizeof(float);
+    STES_CHECK(lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_stem_conv: image too wide");
+    const bool vec = W % 4 == 0 && (uintptr_t)x % (x_is_u8 ? 4 : 16) == 0;
+    const bool det_on = col_sum != nullptr;
+#define STEM_LAUNCH(U, E, V) do { \
+        const long cap = stem_resident(stem_conv_kernel<U, E, V>, lds); \
+        const unsigned blocks = (unsigned)(gm.units < cap ? gm.units : cap); \
+        const StesDet det = det_on ? stes_det_take(blocks) : StesDet{nullptr, 0u, 0u}; \
+        hipLaunchKernelGGL((stem_conv_kernel<U, E, V>), dim3(blocks), dim3(256), lds, S(stream), x, nm, (const bf16*)w_bf, \
+            (bf16*)patches, (bf16*)out, col_sum, col_sumsq, e_scale, e_shift, (bf16*)e_slice, e_slice_n, gm, det); } while (0)
+#define STEM_LAUNCH_V(U, E) do { if (vec) STEM_LAUNCH(U, E, true); else STEM_LAUNCH(U, E, false); } while (0)
+    if (x_is_u8) { if (eval) STEM_LAUNCH_V(true, true); else STEM_LAUNCH_V(true, false); }
+    else { if (eval) STEM_LAUNCH_V(false, true); else STEM_LAUNCH_V(false, false); }
+#undef STEM_LAUNCH_V
+#undef STEM_LAUNCH
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

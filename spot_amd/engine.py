@@ -735,23 +735,23 @@ class Engine:
         if train:
             self._stats[:self._stats_used].zero_()
         self._x = x
+        mean = std = None
         if u8:
             mean = (C.c_float * 3)(*self.input_mean[:Cin], *([0.0] * (3 - Cin)))
             std = (C.c_float * 3)(*self.input_std[:Cin], *([1.0] * (3 - Cin)))
-            lib.call("stes_im2col_stem_u8", p(x), p(self.patches), mean, std, B, T, Tx, Cin, H, W)
-        else:
-            lib.call("stes_im2col_stem", p(x), p(self.patches), N, Cin, H, W)
-        st = (self.bn0.sum, self.bn0.sumsq) if train else None
         blocks = self.blocks
-        if not train and lib.gemm_has_tail(self.M0, 32, 32):
-            # evaluation: stem BatchNorm + ReLU (and the first block's gated-shift slice) in the stem GEMM's store phase
-            self.bn0.finalize(self.M0, train)
-            slc = (blocks[0].Xc, blocks[0].fold) if blocks[0].kind == "gsm" else (None, 0)
-            lib.gemm(self.patches, self.stem.w_bf, self.X0, self.M0, 32, 32, tail=(self.bn0.scale, self.bn0.shift, None, None, None) + slc)
-        else:
-            lib.gemm(self.patches, self.stem.w_bf, self.c0, self.M0, 32, 32, stats=st)
+        if train:
+            # one pass: patches (the weight gradient reads them), the raw output and its column statistics
+            lib.call("stes_stem_conv", p(x), int(u8), mean, std, p(self.stem.w_bf), p(self.patches), p(self.c0), p(self.bn0.sum),
+                     p(self.bn0.sumsq), None, None, None, 0, B, T, Tx, Cin, H, W)
             self.bn0.finalize(self.M0, train)
             self.bn_act(self.c0, self.bn0, None, None, None, self.X0, blocks[0], train, self.M0, 32)
+        else:
+            # evaluation: BatchNorm + ReLU (and the first block's gated-shift slice) in the convolution's store phase
+            self.bn0.finalize(self.M0, train)
+            slc, fold = (blocks[0].Xc, blocks[0].fold) if blocks[0].kind == "gsm" else (None, 0)
+            lib.call("stes_stem_conv", p(x), int(u8), mean, std, p(self.stem.w_bf), None, p(self.X0), None, None, p(self.bn0.scale),
+                     p(self.bn0.shift), p(slc), fold, B, T, Tx, Cin, H, W)
         X = self.X0
         for i, blk in enumerate(blocks):
             X = blk.forward(X, train, blocks[i + 1] if i + 1 < len(blocks) else None)

@@ -97,6 +97,7 @@ _SIGS = {
     "stes_conv3x3g_wgrad": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stes_im2col_stem_u8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_stem_conv": [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_augment_u8": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gsm_prep": [_P, _P, _I32, _P],
     "stes_gsm_gate": [_P, _P, _P, _P, _P, _P, _P, _P],
@@ -207,6 +208,13 @@ def _conv_bytes(a):
     return 2 * c * n * (hi * wi + ho * wo)
 
 
+def _stem_bytes(a):
+    e_slice, e_slice_n, b, t, tv, cin, h, w = a[11:19]
+    pix = b * t * ((h + 1) // 2) * ((w + 1) // 2)
+    out = 64 * pix * (1 if a[9] is not None else 2) + (2 * e_slice_n * pix if e_slice is not None else 0)
+    return b * tv * cin * h * w * (1 if a[1] else 4) + out
+
+
 # entry point -> (kernel name, algorithmic bytes of one call): every operand read once, every result written once
 _KERNEL_OF = {
     "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
@@ -220,6 +228,9 @@ _KERNEL_OF = {
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
     "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
+    # (x, x_is_u8, mean, std, w, patches, out, sums..., e_scale, e_shift, e_slice, e_slice_n, B, T, Tv, Cin, H, W)
+    "stes_stem_conv": (lambda a: "stem_conv_kernel<%s, %s>" % ("true" if a[1] else "false", "true" if a[9] is not None else "false"),
+                       _stem_bytes),
     # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums..., x_bits): every operand once (the
     # mask as X, 2 bytes per element, or as bits, an eighth of a byte)
     "stes_block_in_grad": (lambda a: "block_in_grad_kernel<%s>" % ("true" if a[14] is not None else "false"),

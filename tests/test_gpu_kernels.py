@@ -197,6 +197,50 @@ def test_im2col_stem_u8_equals_fp32_path_on_the_loaders_tensor(B, T, Tv, H, W):
         lib.call("stes_im2col_stem_u8", lib.ptr(dev(u)), lib.ptr(b), m3, s3, B, Tv - 1 if Tv > 1 else 0, Tv, 3, H, W)
 
 
+@pytest.mark.parametrize("B,T,Tv,H,W,u8", [(2, 3, 3, 12, 10, False), (3, 4, 2, 9, 15, True), (1, 5, 1, 7, 7, True), (2, 2, 2, 64, 64, False),
+                                             (1, 2, 2, 224, 224, True)])
+def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
+    """The one-pass stem convolution gives, bit for bit, the patches of stes_im2col_stem(_u8), and the output / column
+    statistics / evaluation tail of the product of those patches with the weight matrix."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(41)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    M = B * T * Ho * Wo
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    m3, s3 = (C.c_float * 3)(*mean.tolist()), (C.c_float * 3)(*std.tolist())
+    w = torch.zeros(32, 32); w[:, :27] = torch.randn(32, 27, generator=g) * 0.3
+    wb = dev(w.to(BF))
+    pat = torch.full((M, 32), 7.0, dtype=BF, device="cuda")
+    if u8:
+        x = dev(torch.randint(0, 256, (B, Tv, 3, H, W), generator=g, dtype=torch.uint8))
+        lib.call("stes_im2col_stem_u8", lib.ptr(x), lib.ptr(pat), m3, s3, B, T, Tv, 3, H, W)
+    else:
+        x = dev(torch.randn(B * T, 3, H, W, generator=g))
+        lib.call("stes_im2col_stem", lib.ptr(x), lib.ptr(pat), B * T, 3, H, W)
+    torch.cuda.synchronize()
+    ref = (pat.float() @ wb.float().t()).to(BF)                       # fp32 products of bf16 operands, rounded once
+    got_p = torch.full_like(pat, 9.0); got = torch.full_like(pat, 9.0)
+    ssum = torch.zeros(32, device="cuda"); ssq = torch.zeros(32, device="cuda")
+    args = (lib.ptr(x), int(u8), m3 if u8 else None, s3 if u8 else None, lib.ptr(wb))
+    lib.call("stes_stem_conv", *args, lib.ptr(got_p), lib.ptr(got), lib.ptr(ssum), lib.ptr(ssq), None, None, None, 0, B, T, Tv, 3, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(got_p.view(torch.int16), pat.view(torch.int16))
+    # (the accumulation order over k differs between MFMA shapes: one bf16 ulp)
+    close(got.float().cpu(), ref.float().cpu(), 2e-2, 1e-2)
+    close(ssum.cpu(), got.float().sum(0).cpu(), 1e-3 * M ** 0.5, 1e-4)
+    close(ssq.cpu(), (got.float() ** 2).sum(0).cpu(), 1e-3 * M ** 0.5, 1e-4)
+    # evaluation form: relu(scale * c + shift) and the first 8 channels as a compact slice; no patches
+    sc = dev(torch.rand(32, generator=g) + 0.5); sh = dev(torch.randn(32, generator=g) * 0.2)
+    ev = torch.full_like(pat, 9.0); sl = torch.full((M, 8), 9.0, dtype=BF, device="cuda")
+    lib.call("stes_stem_conv", *args, None, lib.ptr(ev), None, None, lib.ptr(sc), lib.ptr(sh), lib.ptr(sl), 8, B, T, Tv, 3, H, W)
+    torch.cuda.synchronize()
+    want = torch.relu((pat.float() @ wb.float().t()) * sc + sh)
+    close(ev.float().cpu(), want.cpu(), 2e-2, 1e-2)
+    assert torch.equal(sl.view(torch.int16), ev[:, :8].contiguous().view(torch.int16))
+    with pytest.raises(lib.StesError):
+        lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
+
+
 def test_bn_finalize_and_act_residual():
     from spot_amd import lib
     g = torch.Generator().manual_seed(5)

@@ -330,10 +330,18 @@ def test_sliding_window_events_match_oracle():
     print("min top-2 score margin in the oracle:", margin.min(), " max |score diff|:", np.abs(scores - osc).max())
     # the claim "identical event frames" is made where no argmax can flip: two scores that each move by at most the largest
     # score error e can only change order when they are no more than 2e apart
-    assert margin.min() > 2 * np.abs(scores - osc).max()
+    err = np.abs(scores - osc).max()
+    assert margin.min() > 2 * err
     got = [(e["frame"], e["label"]) for e in ev[0]["events"]]
     want = [(e["frame"], e["label"]) for e in oev]
-    assert got == want
+    # ... and where non-maximum suppression is decisive by the same rule: an event may sit on another frame than the oracle's
+    # only when both frames carry the label, lie within the suppression window and score within 2e of each other in the oracle
+    only_got, only_want = sorted(set(got) - set(want)), sorted(set(want) - set(got))
+    assert len(got) == len(want) and len(only_got) == len(only_want)
+    for (fg, lg), (fw, lw) in zip(only_got, only_want):
+        c = classes.index(lg) + 1
+        assert lg == lw and abs(fg - fw) <= 3 and abs(osc[fg, c] - osc[fw, c]) <= 2 * err, ((fg, lg), (fw, lw), osc[fg, c], osc[fw, c], err)
+    print("events on other frames than the oracle's (suppression ties within 2e):", list(zip(only_got, only_want)))
     # the two-GPU sharding of the windows gives the same result as one GPU (replicas only, host gather)
     parts = []
     for r in range(2):
