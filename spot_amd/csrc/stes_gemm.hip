@@ -457,6 +457,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     TileBuf* Ps = reinterpret_cast<TileBuf*>(wg_smem);                            // [2]
     TileBuf* Qs = Ps + 2;                                                        // [2]
     float* bias_acc = reinterpret_cast<float*>(Qs + 2);                          // [T]
+    float* qaff = bias_acc + T;                                                  // [2][T]: the Q prologue's scale, shift for this tile's columns
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int W2N = WAVES / 2;
@@ -512,11 +513,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             pal[i] = on ? p.bn_alpha[c1 + i] : 1.f; pbe[i] = on ? p.bn_beta[c1 + i] : 0.f; pde[i] = on ? p.bn_delta[c1 + i] : 0.f;
         }
     }
-    float qsc[8], qsh[8];      // this thread's 8 columns of the prologue's scale / shift
+    // Small tile: the prologue's scale / shift live in LDS (read when a staged chunk is transformed), so that the registers hold
+    // the squeeze-excite gate values of the chunks in flight instead -- those come from memory and are fetched with the operands
+    // (64 x 64 at 3.2 M rows: 155 us instead of 175).  The capped large tile has no registers for them (the same change spills
+    // and measures 4 % slower at 768 x 768): it keeps scale / shift in registers and reads the gate when it transforms.
+    constexpr bool GATE_AHEAD = T == 64;
+    float qsc[GATE_AHEAD ? 1 : 8], qsh[GATE_AHEAD ? 1 : 8];
+    if constexpr (GATE_AHEAD) {
+        if (has_affine && tid < T) {
+            const bool on = n2_0 + tid < p.N2;
+            qaff[tid] = on ? p.q_scale[n2_0 + tid] : 1.f; qaff[T + tid] = on ? p.q_shift[n2_0 + tid] : 0.f;
+        }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { qsc[i] = (has_affine && c2_ok) ? p.q_scale[c2 + i] : 1.f; qsh[i] = (has_affine && c2_ok) ? p.q_shift[c2 + i] : 0.f; }
+        for (int i = 0; i < 8; ++i) { qsc[i] = (has_affine && c2_ok) ? p.q_scale[c2 + i] : 1.f; qsh[i] = (has_affine && c2_ok) ? p.q_shift[c2 + i] : 0.f; }
+    }
     bf16x8 rp[LOADS], rq[LOADS], rr[T == 64 ? LOADS : 1];
-    long qm[LOADS];   // logical row of each staged q chunk (for the gate lookup)
+    f32x4 rg[GATE_AHEAD ? LOADS : 1][2];   // gate values of each staged q chunk's 8 columns
+    long qm[LOADS];                        // logical row of each staged q chunk
     auto gload = [&](long mb) {
 #pragma unroll
         for (int h = 0; h < LOADS; ++h) {
@@ -535,6 +549,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 if (c2_ok) rq[h] = (c2 < p.k0) ? *reinterpret_cast<const bf16x8*>(Q0 + src * p.ldq0 + c2)
                                                : *reinterpret_cast<const bf16x8*>(Q + src * p.ldq + c2);
                 else rq[h] = zero8();
+                if (GATE_AHEAD && has_gate && c2_ok) {
+                    const float* g = p.q_gate + (long)fdiv((uint32_t)m, dv.gate) * p.N2 + c2;
+                    rg[h][0] = *reinterpret_cast<const f32x4*>(g); rg[h][1] = *reinterpret_cast<const f32x4*>(g + 4);
+                }
             } else {
                 rp[h] = zero8(); rq[h] = zero8();
             }
@@ -548,17 +566,33 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             if ((has_affine || has_gate) && qm[h] < m_end && c2_ok) {
                 float f[8];
                 unpack8(v, f);
-                if (has_affine) {
+                if constexpr (GATE_AHEAD) {
+                    if (has_affine) {
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(qaff + lc * 8), s1 = *reinterpret_cast<const f32x4*>(qaff + lc * 8 + 4);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(qaff + T + lc * 8), b1 = *reinterpret_cast<const f32x4*>(qaff + T + lc * 8 + 4);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f[i] = f[i] * qsc[i] + qsh[i];
-                        if (p.q_relu) f[i] = fmaxf(f[i], 0.f);
+                        for (int i = 0; i < 8; ++i) {
+                            f[i] = f[i] * (i < 4 ? s0[i & 3] : s1[i & 3]) + (i < 4 ? b0[i & 3] : b1[i & 3]);
+                            if (p.q_relu) f[i] = fmaxf(f[i], 0.f);
+                        }
                     }
-                }
-                if (has_gate) {
-                    const float* g = p.q_gate + (long)fdiv((uint32_t)qm[h], dv.gate) * p.N2 + c2;
+                    if (has_gate) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) f[i] *= g[i];
+                        for (int i = 0; i < 8; ++i) f[i] *= rg[h][i >> 2][i & 3];
+                    }
+                } else {
+                    if (has_affine) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            f[i] = f[i] * qsc[i] + qsh[i];
+                            if (p.q_relu) f[i] = fmaxf(f[i], 0.f);
+                        }
+                    }
+                    if (has_gate) {
+                        const float* g = p.q_gate + (long)fdiv((uint32_t)qm[h], dv.gate) * p.N2 + c2;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] *= g[i];
+                    }
                 }
                 v = pack8(f);
             }
@@ -580,6 +614,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     };
 
     gload(m_begin);
+    if (GATE_AHEAD && has_affine) __syncthreads();       // the scale / shift columns are in LDS
     lstore(0);
     __syncthreads();
     int buf = 0;
@@ -837,7 +872,7 @@ static size_t wgrad_lds_bytes() {
     static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    160 * 1024) == hipSuccess;
     (void)raised;
-    return (size_t)4 * (T == 128 ? 64 : 32) * (T + 16) * sizeof(bf16) + T * sizeof(float);
+    return (size_t)4 * (T == 128 ? 64 : 32) * (T + 16) * sizeof(bf16) + 3 * T * sizeof(float);
 }
 
 }  // namespace

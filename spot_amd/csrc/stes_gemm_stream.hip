@@ -75,7 +75,7 @@ __device__ __forceinline__ void gemm_stream_body(const stes_gemm_args& p, int ro
     float* red = de_s + K;                      // [2][NB]
     float* epi_l = red + 2 * NB;                // [4][NB]: block-tail epilogue scale, shift, residual scale, residual shift
     constexpr int WG_PSUB = K / 16, WG_QSUB = NB / 16;                         // [32][16] bf16 sub-tiles (1 KiB each) of pro(A) and of Q
-    unsigned char* wgl = reinterpret_cast<unsigned char*>(epi_l + 4 * NB) + wave * (WG_PSUB + WG_QSUB) * 1024;
+    unsigned char* wgl = reinterpret_cast<unsigned char*>(epi_l + (TAIL ? 4 * NB : 0)) + wave * (WG_PSUB + WG_QSUB) * 1024;
     // AFF: this wave's copy of the gate rows of the (at most two) images its current tile touches, or ones without a gate.
     // It lives in the wave's output staging buffer: the gate is read in the k loop, the staging buffer in the tile epilogue.
     float* gl = reinterpret_cast<float*>(stage);
@@ -499,7 +499,7 @@ static int stream_residency(size_t lds) {
 template <int NI, int WAVES, int PRO, int NK, int TA, int J, bool WG = false, bool TAIL = false>
 static void launch(const stes_gemm_args* a, hipStream_t stream, const StreamDivs& dv) {
     constexpr int NB = NI * 16, K = NK * 32;
-    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + 6 * NB) * sizeof(float) +
+    const size_t lds = (size_t)NB * (2 * K + 32) + (size_t)WAVES * 16 * (NB * 2 + 16) + (size_t)(3 * K + (TAIL ? 6 : 2) * NB) * sizeof(float) +
                        (WG ? (size_t)WAVES * (K / 16 + NB / 16) * 1024 : 0);
     const int n_slices = a->N / NB;
     const int row_tiles = stes_div_up(a->M, 16 * J);
@@ -553,7 +553,7 @@ static bool launch_k(const stes_gemm_args* a, hipStream_t stream, const StreamDi
 int stes_stream_slice(const stes_gemm_args* a) {
     int nb = 0;
     if (a->N == 32 || a->N == 64 || a->N == 128 || a->N == 160) nb = a->N;
-    else if (a->N == 320) nb = 160;
+    else if (a->N == 320) nb = 160;    // (80-column slices, two workgroups per CU: 99 us instead of 81 -- the operand loads double)
     else if (a->N % 128 == 0 && a->N <= 1024) nb = 128;     // wide layers with a short K (stage 4's first 1x1 conv): 128-column slices
     const bool bnb = a->a_raw != nullptr;
     const bool k_ok = a->K == 320 || a->K == 128 || a->K == 64 || (a->K == 32 && !bnb);

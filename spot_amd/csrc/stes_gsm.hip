@@ -13,6 +13,7 @@
 //            transposed through LDS with ds_read_b64_tr_b16), gradient at the BatchNorm3d output (27-tap gather of the
 //            gate gradient staged in LDS, weights scalar), final input gradient (elementwise).
 #include "stes_common.h"
+#include "stes_gsm_small.h"
 
 namespace {
 
@@ -1376,7 +1377,8 @@ extern "C" int stes_gsm_forward(const uint16_t* Xc, const float* scale, const fl
                                 float* gate, uint16_t* G, const stes_gsm_geom* g, void* stream) {
     int rc = check_geom(g); if (rc) return rc;
     STES_CHECK(Xc && scale && shift && wt && b3d && gate && G, STES_ERR_ARG, "stes_gsm_forward: null pointer");
-    STES_CHECK(g->fold >= 32, STES_ERR_UNSUPPORTED, "stes_gsm_forward: built for fold >= 32 (run stes_gsm_gate + stes_gsm_shift)");
+    // narrow slices (the high-resolution stages): their own kernel, taps x channels as the contraction dimension
+    if (g->fold < 32) return stes_gsm_small_forward(Xc, scale, shift, wt, b3d, gate, G, g->B, g->T, g->H, g->W, g->fold, stream);
     const Geom gm = to_geom(g);
     FwdTile ft;
     ft.TH = fused_tile_rows(gm);

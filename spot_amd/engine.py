@@ -171,7 +171,9 @@ class Block:
             geom = lib.gsm_geom(self.N // self.T, self.T, self.Hi, self.Wi, self.fold)
             self.geom = geom
             self.bng.finalize(Mi, train)
-            if self.fold >= 80:          # gate conv (MFMA) and shift in one kernel (measured: faster from fold 80 up, slower at 32)
+            # gate conv (MFMA) and shift in one kernel: the narrow slices of the large maps (230 us instead of 360 at fold 8, 129
+            # instead of 141 at fold 16) and the wide ones of the small maps (measured: faster from fold 80 up, slower at 32)
+            if self.fold >= 80 or self.fold <= 16:
                 lib.call("stes_gsm_forward", p(self.Xc), p(self.bng.scale), p(self.bng.shift), p(self.wt), p(self.gsm.conv3D.bias),
                          p(self.gate), p(self.G), C.byref(geom))
             else:

@@ -215,6 +215,26 @@ def _stem_bytes(a):
     return b * tv * cin * h * w * (1 if a[1] else 4) + out
 
 
+def _geom_of(a):
+    """(rows, fold) of the gated-shift geometry passed by reference as the last argument."""
+    g = a[-1]._obj
+    return g.B * g.T * g.H * g.W, g.fold
+
+
+def _gsm_bytes(slices, gates):
+    """Algorithmic bytes of a gated-shift kernel: `slices` passes over the bf16 slice [M][fold], `gates` over an fp32 [M][2]."""
+    def f(a):
+        m, fold = _geom_of(a)
+        return slices * m * fold * 2 + gates * m * 8
+    return f
+
+
+def _bn_act_bytes(a):
+    # (c, scale, shift, res, rscale, rshift, out, sum, sumsq, stat_c, slice_out, M, C, relu_bits)
+    m, c = a[11], a[12]
+    return 2 * m * c * (2 + (a[3] is not None)) + (2 * m * a[9] if a[10] is not None else 0) + (m * c // 8 if a[13] is not None else 0)
+
+
 # entry point -> (kernel name, algorithmic bytes of one call): every operand read once, every result written once
 _KERNEL_OF = {
     "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
@@ -233,6 +253,21 @@ _KERNEL_OF = {
                        _stem_bytes),
     # (dY, ldy, dXf, fold, resid, ms, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, sums..., x_bits): every operand once (the
     # mask as X, 2 bytes per element, or as bits, an eighth of a byte)
+    # gated shift: passes over the compact slice and over the gate-sized fp32 tensors (gate, gate gradient)
+    "stes_gsm_forward": (lambda a: "gsm_fwd_small_kernel<%d>" % _geom_of(a)[1] if _geom_of(a)[1] < 32 else
+                         "gsm_fwd_fused_kernel<%d>" % ((_geom_of(a)[1] // 2 + 31) // 32), _gsm_bytes(2, 1)),
+    "stes_gsm_gate": ("gsm_gate_kernel", _gsm_bytes(1, 1)),
+    "stes_gsm_shift": (lambda a: "gsm_shift_kernel<%d>" % (4 if _geom_of(a)[1] == 8 else 8), _gsm_bytes(2, 1)),
+    "stes_gsm_bwd_gate": (lambda a: "gsm_bwd_gate_kernel<4>" if _geom_of(a)[1] == 8 else "gsm_bwd_gate_rows_kernel", _gsm_bytes(2, 2)),
+    "stes_gsm_bwd_wgrad": ("gsm_bwd_wgrad_kernel", _gsm_bytes(1, 1)),
+    "stes_gsm_dxbn": (lambda a: "gsm_dxbn_rows_kernel<%d>" % _geom_of(a)[1] if _geom_of(a)[1] <= 16 else "gsm_dxbn_kernel<8>", _gsm_bytes(2, 1)),
+    "stes_gsm_bwd_conv": (lambda a: "gsm_bwd_conv_kernel<%d>" % ((_geom_of(a)[1] // 2 + 15) // 16), _gsm_bytes(2, 1)),
+    "stes_gsm_bwd_dx": (lambda a: "gsm_bwd_dx_kernel<%d>" % (4 if _geom_of(a)[1] == 8 else 8), _gsm_bytes(4, 1)),
+    "stes_bn_act_residual": ("bn_act_residual_kernel", _bn_act_bytes),
+    # (c, scale, shift, mul, out, out_bf16, N, HW, C, norm): the map once (twice with a multiplier)
+    "stes_chan_pool": ("chan_pool_kernel", lambda a: 2 * a[6] * a[7] * a[8] * (1 + (a[3] is not None))),
+    # (c2, scale, shift, dA3, S, dgate, gate, dpre, N, HW, C): the raw map and the gradient once each
+    "stes_se_bwd_pool": ("se_bwd_pool_kernel", lambda a: 4 * a[8] * a[9] * a[10]),
     "stes_block_in_grad": (lambda a: "block_in_grad_kernel<%s>" % ("true" if a[14] is not None else "false"),
                            lambda a: 2 * a[12] * a[13] * (2 + (a[14] is not None) + (a[15] is not None))
                            + (a[12] * a[13] // 8 if a[19] is not None else 2 * a[12] * a[13])

@@ -491,7 +491,7 @@ def _gsm_run(z, mode, fused=False):
         dw = torch.zeros_like(w3d); db = torch.zeros(2, device="cuda")
         dxbn = torch.empty(M, fold, dtype=BF, device="cuda")
         sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
-        if fused:
+        if fused and fold >= 32:                                 # (narrower slices: one-kernel forward, backward kernel sequence)
             ws = torch.zeros(lib.lib().stes_gsm_bwd_conv_ws_floats(fold), device="cuda")
             lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn),
                      lib.ptr(sd), lib.ptr(sdx), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), C.byref(geom))
@@ -592,6 +592,38 @@ def test_gsm_fused_forward_and_backward_conv(B, T, H, W, fold):
             assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 8e-3, (name, k)
 
 
+@pytest.mark.parametrize("B,T,H,W,fold", [(2, 3, 9, 20, 8), (1, 1, 5, 7, 8), (2, 9, 9, 30, 8), (1, 5, 13, 50, 16), (1, 11, 40, 36, 16), (1, 64, 16, 16, 16),
+                                          (1, 70, 3, 112, 8), (1, 2, 24, 112, 8), (2, 7, 20, 56, 16), (1, 4, 1, 1, 8), (1, 6, 2, 100, 16)])
+def test_gsm_narrow_slice_forward_in_one_kernel(B, T, H, W, fold):
+    """stes_gsm_forward on slices of 8 and 16 channels (frame segments with their four extra frames, ragged row tiles, rows
+    that are not a multiple of 16 positions, single frames and single pixels): the gate against conv3d (reference
+    model/shift.py:108-110) on the same bf16-rounded operands, the output bit for bit against the shift kernel run on the
+    kernel's own gate values."""
+    from spot_amd import lib
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + T + H + W + fold)
+    half, M = fold // 2, B * T * H * W
+    Xc = torch.randn(M, fold, generator=g).to(BF)
+    sc, sh = torch.rand(fold, generator=g) + 0.5, torch.randn(fold, generator=g) * 0.3
+    w3d = torch.randn(2, half, 3, 3, 3, generator=g) / (27 * half) ** 0.5
+    b3d = torch.randn(2, generator=g) * 0.1
+    wt = torch.empty(27 * fold, dtype=BF, device="cuda")
+    lib.call("stes_gsm_prep", lib.ptr(dev(w3d)), lib.ptr(wt), fold)
+    gate = torch.full((M, 2), 9.0, device="cuda")
+    G = torch.full((M, fold), 9.0, dtype=BF, device="cuda")
+    geom = lib.gsm_geom(B, T, H, W, fold)
+    dXc = dev(Xc)
+    lib.call("stes_gsm_forward", lib.ptr(dXc), lib.ptr(dev(sc)), lib.ptr(dev(sh)), lib.ptr(wt), lib.ptr(dev(b3d)), lib.ptr(gate), lib.ptr(G), C.byref(geom))
+    torch.cuda.synchronize()
+    xb = torch.relu(Xc.float() * sc + sh).to(BF).float().view(B, T, H, W, fold).permute(0, 4, 1, 2, 3)
+    ref = torch.tanh(F.conv3d(xb, w3d.to(BF).float(), b3d, padding=1, groups=2)).permute(0, 2, 3, 4, 1).reshape(M, 2)
+    close(gate, ref, 1e-4, 1e-4)
+    G2 = torch.empty_like(G)
+    lib.call("stes_gsm_shift", lib.ptr(dXc), lib.ptr(gate), lib.ptr(G2), C.byref(geom))
+    torch.cuda.synchronize()
+    assert torch.equal(G.view(torch.int16), G2.view(torch.int16))
+
+
 @pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
 @pytest.mark.parametrize("mode", ["train", "eval"])
 @pytest.mark.parametrize("fused", [False, True])
@@ -599,9 +631,7 @@ def test_gsm_vs_reference_golden(golden, fold, mode, fused):
     """Inputs of the golden vectors rounded to bf16 (the kernels' storage type); expected values are the
     reference's fp32 outputs -> tolerance 2 bf16 ulp + the input rounding + the gate conv weights rounded to bf16 (like
     every other conv weight on the path; up to 2592 products per gate value at fold 192).  fused: the one-kernel forward and
-    gate-conv backward (built for fold >= 32)."""
-    if fused and fold < 32:
-        pytest.skip("the fused kernels are built for fold >= 32")
+    (from fold 32 up) the one-kernel gate-conv backward."""
     z = golden(f"gsm_f{fold}_{mode}_rand")
     r = _gsm_run(z, mode, fused)
     close(r["y"], torch.from_numpy(z["y"]), 2e-2, 5e-2)
@@ -615,7 +645,8 @@ def test_gsm_vs_reference_golden(golden, fold, mode, fused):
             assert float((a - b).norm() / (b.norm() + 1e-6)) < 3e-2, k
 
 
-@pytest.mark.parametrize("fold,fused", [(8, False), (16, False), (32, False), (80, False), (192, False), (32, True), (80, True), (192, True)])
+@pytest.mark.parametrize("fold,fused", [(8, False), (16, False), (32, False), (80, False), (192, False), (8, True), (16, True), (32, True), (80, True),
+                                        (192, True)])
 def test_gsm_zero_gate_shift_indexing_bit_exact(golden, fold, fused):
     """conv3D = 0 (the reference's init): output is exactly the within-group channel interleave of the bf16 input."""
     z = golden(f"gsm_f{fold}_eval_zero")

@@ -14,6 +14,11 @@ p = lib.ptr
 
 
 def run(name, fn, byt, reps=10):
+    try:
+        fn()
+    except lib.StesError as err:
+        print("  %-34s not built for this shape (%s)" % (name, str(err)[:60]))
+        return
     for _ in range(2):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,10 +32,11 @@ def run(name, fn, byt, reps=10):
 
 
 ONLY = os.environ.get("GSM_ONLY")
-for (B, T, H, W, fold) in [(16, 64, 28, 28, 32), (16, 64, 14, 14, 80), (16, 64, 7, 7, 192)]:
+SHAPES = [(16, 64, 112, 112, 8, 1), (16, 64, 56, 56, 16, 1), (16, 64, 28, 28, 32, 3), (16, 64, 14, 14, 80, 8), (16, 64, 7, 7, 192, 1)]
+for (B, T, H, W, fold, n_blocks) in SHAPES:
     M = B * T * H * W
     half = fold // 2
-    print("B=%d T=%d %dx%d fold=%d (Xc %.1f MB)" % (B, T, H, W, fold, M * fold * 2 / 1e6))
+    print("B=%d T=%d %dx%d fold=%d (Xc %.1f MB), %d block(s) of the network" % (B, T, H, W, fold, M * fold * 2 / 1e6, n_blocks))
     Xc = torch.randn(M, fold, device="cuda").to(BF)
     sc, sh = torch.rand(fold, device="cuda") + 0.5, torch.randn(fold, device="cuda") * 0.3
     w3d = torch.randn(2, half, 27, device="cuda") / (27 * half) ** 0.5
@@ -56,6 +62,18 @@ for (B, T, H, W, fold) in [(16, 64, 28, 28, 32), (16, 64, 14, 14, 80), (16, 64, 
         lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(sc), p(sh), p(w3d), p(dxbn), C.byref(geom))
         lib.bn_bwd_reduce(dxbn, Xc, M, fold, [sd, sdx])
 
+    dG = torch.randn(M, fold, device="cuda").to(BF)
+    dXf = torch.empty(M, fold, dtype=BF, device="cuda")
+    al, be, de = torch.rand(fold, device="cuda"), torch.rand(fold, device="cuda"), torch.rand(fold, device="cuda")
+    if not ONLY or ONLY == "each":
+        run("gate", lambda: lib.call("stes_gsm_gate", p(Xc), p(sc), p(sh), p(wt), p(b3d), p(gate), C.byref(geom)), unit + 8.0 * M)
+        run("shift", lambda: lib.call("stes_gsm_shift", p(Xc), p(gate), p(G), C.byref(geom)), 2 * unit + 8.0 * M)
+        run("bwd_gate", lambda: lib.call("stes_gsm_bwd_gate", p(dG), p(Xc), p(gate), p(dpre), C.byref(geom)), 2 * unit + 16.0 * M)
+        run("bwd_wgrad", lambda: lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(sc), p(sh), p(dw), p(db), C.byref(geom)), unit + 8.0 * M)
+        run("dxbn", lambda: lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(sc), p(sh), p(w3d), p(dxbn), C.byref(geom)), 2 * unit + 8.0 * M)
+        run("bn_bwd_reduce", lambda: lib.bn_bwd_reduce(dxbn, Xc, M, fold, [sd, sdx]), 2 * unit)
+        run("bwd_dx", lambda: lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(gate), p(dxbn), p(al), p(be), p(de), p(dXf), C.byref(geom)),
+            4 * unit + 8.0 * M)
     if not ONLY or ONLY == "fwd":
         run("gate + shift", old_fwd, 2 * unit)
         run("gsm_forward", lambda: lib.call("stes_gsm_forward", p(Xc), p(sc), p(sh), p(wt), p(b3d), p(gate), p(G), C.byref(geom)), 2 * unit)

@@ -17,8 +17,30 @@ SHAPES = [  # (what, M, N1 (dY cols), N2 (X cols), calls per step)
     ("gru wih 4608x768", F, 4608, 768, 1), ("gru whh 2304x768", F, 2304, 768, 2), ("loc 2304x768", F, 2304, 768, 1), ("loc 768x2304", F, 768, 2304, 1),
     ("se s3 80x320", F, 80, 320, 8), ("se s3 320x80", F, 320, 80, 8),
 ]
+# the in-step forms of the conv3 weight gradients: Q = relu(bn2(c2)) * squeeze-excite gate, (what, M, N1, N2, calls, rows per gate row)
+PRO_SHAPES = [("s2 conv3 128x128 bn+relu+gate", F * 28 * 28, 128, 128, 3, 784), ("s4 conv3 768x768 bn+relu+gate", F * 7 * 7, 768, 768, 2, 49),
+              ("s4.b1 conv1 768x320 plain", F * 14 * 14, 768, 320, 1, 0), ("s1 conv3 64x64 bn+relu+gate", F * 56 * 56, 64, 64, 1, 3136)]
 torch.cuda.init()
 tot = 0.0
+for what, M, N1, N2, calls, grp in PRO_SHAPES if "--pro" in sys.argv else []:
+    P = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
+    Q = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
+    dW = torch.zeros(N1, N2, device="cuda")
+    sc, sh = torch.rand(N2, device="cuda") + 0.5, torch.randn(N2, device="cuda")
+    kw = dict(scale=sc, shift=sh, relu=True, gate=torch.rand(M // grp, N2, device="cuda"), gate_group=grp) if grp else {}
+    for _ in range(3):
+        lib.wgrad(P, Q, dW, M, N1, N2, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        lib.wgrad(P, Q, dW, M, N1, N2, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print("%-32s M=%8d  %7.1f us  %6.0f GB/s  %6.1f TFLOP/s  x%d" % (what, M, us, 2.0 * M * (N1 + N2) / us / 1e3, 2.0 * M * N1 * N2 / us / 1e6, calls), flush=True)
+    del P, Q, dW
+if "--pro" in sys.argv:
+    sys.exit(0)
 for what, M, N1, N2, calls in SHAPES:
     P = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
     Q = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
