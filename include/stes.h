@@ -297,7 +297,10 @@ int stes_augment_u8(const uint8_t* x, float* out_f32, uint8_t* out_u8, const flo
  *                       the 3x3 spatial taps as a gather sum in LDS), the shift follows in the same workgroup.  fold >= 32.
  *   stes_gsm_bwd_conv : backward of the gate conv in one kernel: dxbn (as stes_gsm_dxbn), the conv3D weight/bias gradient
  *                       (as stes_gsm_bwd_wgrad) and the BatchNorm3d-backward sums s_dy += sum dxbn, s_dyr += sum dxbn * x
- *                       (as stes_bn_bwd_reduce on dxbn, Xc).  fold >= 32.  ws: NULL, or stes_gsm_bwd_conv_ws_floats(fold)
+ *                       (as stes_bn_bwd_reduce on dxbn, Xc).  Slices of 8 and 16 channels: dxbn and the sums are one kernel
+ *                       and the conv3D gradients a second one behind it, skipped when dw and db are NULL (a caller that runs
+ *                       stes_gsm_bwd_wgrad on another stream); ws is not used.  fold >= 32: dw and db are required; ws: NULL,
+ *                       or stes_gsm_bwd_conv_ws_floats(fold)
  *                       floats that are ZERO on entry (they are zero again on return): the per-workgroup partial sums then go
  *                       to STES_GSM_WS_REPLICAS copies and a second small launch adds them up -- a thousand workgroups adding
  *                       into the same few KiB serialise in the memory-side atomic units (6x the kernel's time without ws).  */

@@ -1401,8 +1401,15 @@ extern "C" int stes_gsm_bwd_conv(const float* dpre, const uint16_t* Xc, const fl
                                  uint16_t* dxbn, float* s_dy, float* s_dyr, float* dw, float* db, float* ws, const stes_gsm_geom* g,
                                  void* stream) {
     int rc = check_geom(g); if (rc) return rc;
-    STES_CHECK(dpre && Xc && scale && shift && w3d && dxbn && s_dy && s_dyr && dw && db, STES_ERR_ARG, "stes_gsm_bwd_conv: null pointer");
-    STES_CHECK(g->fold >= 32, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: built for fold >= 32 (run stes_gsm_dxbn, stes_gsm_bwd_wgrad, stes_bn_bwd_reduce)");
+    STES_CHECK(dpre && Xc && scale && shift && w3d && dxbn && s_dy && s_dyr, STES_ERR_ARG, "stes_gsm_bwd_conv: null pointer");
+    STES_CHECK((dw == nullptr) == (db == nullptr), STES_ERR_ARG, "stes_gsm_bwd_conv: dw and db come together");
+    if (g->fold < 32) {
+        // narrow slices: dxbn and its sums in one kernel; the conv3D weight gradient (when asked for) is its own kernel behind it
+        rc = stes_gsm_small_dxbn(dpre, Xc, scale, shift, w3d, dxbn, s_dy, s_dyr, g->B, g->T, g->H, g->W, g->fold, stream);
+        if (rc == STES_OK && dw) rc = stes_gsm_bwd_wgrad(dpre, Xc, scale, shift, dw, db, g, stream);
+        return rc;
+    }
+    STES_CHECK(dw && db, STES_ERR_ARG, "stes_gsm_bwd_conv: the wide-slice kernel always computes the conv3D gradients");
     const Geom gm = to_geom(g);
     BwdTile bt;
     bt.TH = fused_tile_rows(gm);

@@ -319,6 +319,132 @@ __global__ __launch_bounds__(256) void gsm_fwd_small_kernel(const bf16* __restri
     }
 }
 
+// ------------------------------------------------------------------ backward of the gate conv on the narrow slices
+// dxbn[m,c] = [bn(x) > 0] * sum_tap w[c][tap] * dpre[m - off(tap), g(c)] (bf16 [M][FOLD]) and the BatchNorm3d-backward sums
+// s_dy += sum_m dxbn, s_dyr += sum_m dxbn * x of the rounded result, in one pass.  A workgroup owns TH full rows of one clip
+// and walks a segment of frames with a three-frame ring of halo tiles of the gate gradient (both groups of a position as one
+// 8-byte entry) in LDS, so the gate gradient is read once.  A thread owns up to four positions with all FOLD channels; the
+// nine (frame, row) tap rows are the outer loop, so that a tap row's 3 x FOLD weights (wave-uniform: scalar registers) are
+// fetched once per frame and workgroup instead of once per position.  The sums stay in registers over the whole segment and
+// leave through one atomic per channel and workgroup.
+constexpr int SB_PPT = 4;        // positions per thread
+
+template <int FOLD>
+__global__ __launch_bounds__(256) void gsm_dxbn_small_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ w3d, bf16* __restrict__ dxbn, float* s_dy,
+                                                             float* s_dyr, SmallGeom gm, StesDet det) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+    constexpr int HALF = FOLD / 2, NCH = FOLD / 8;
+    const int T = gm.T, H = gm.H, W = gm.W, TH = gm.TH, W2 = W + 2, rows = TH + 2;
+    const int h0 = blockIdx.x * TH, t0 = blockIdx.y * gm.TSEG, b = blockIdx.z;
+    const int t1 = t0 + gm.TSEG < T ? t0 + gm.TSEG : T;
+    const int tid = threadIdx.x;
+    const int slot = rows * W2;                                  // entries of a ring slot
+    f32x2* ring = reinterpret_cast<f32x2*>(sg_smem);             // [3][TH + 2][W + 2] (group 0, group 1)
+    float* red = reinterpret_cast<float*>(ring + 3 * slot);      // [2][FOLD]
+    const long plane = (long)H * W;
+    const int npos = TH * W;
+    for (int i = tid; i < 2 * FOLD; i += 256) red[i] = 0.f;
+
+    // this thread's positions: entry of the tile's interior in a slot, offset inside a frame (-1: none / outside the image)
+    int pent[SB_PPT], poff[SB_PPT];
+#pragma unroll
+    for (int j = 0; j < SB_PPT; ++j) {
+        const int o = tid + 256 * j;
+        uint32_t hr, ww;
+        fdivmod((uint32_t)(o < npos ? o : 0), gm.fd_W, hr, ww);
+        pent[j] = ((int)hr + 1) * W2 + (int)ww + 1;
+        poff[j] = (o < npos && h0 + (int)hr < H) ? (h0 + (int)hr) * W + (int)ww : -1;
+    }
+    auto stage = [&](int f) {                                    // gate gradient of frame f -> ring slot f mod 3 (zeros outside)
+        f32x2* dst = ring + ((f + 3) % 3) * slot;
+        const bool live = f >= 0 && f < T;
+        const float* src = dpre + ((long)b * T + (live ? f : 0)) * plane * 2;
+        for (int i = tid; i < slot; i += 256) {
+            uint32_t hr, wp;
+            fdivmod((uint32_t)i, gm.fd_WN, hr, wp);               // (fd_WN: W + 2 here)
+            const int hh = h0 + (int)hr - 1, ww = (int)wp - 1;
+            f32x2 v = {0.f, 0.f};
+            if (live && hh >= 0 && hh < H && ww >= 0 && ww < W) v = *reinterpret_cast<const f32x2*>(src + ((long)hh * W + ww) * 2);
+            dst[i] = v;
+        }
+    };
+    float sdy[FOLD], sdx[FOLD];
+#pragma unroll
+    for (int c = 0; c < FOLD; ++c) { sdy[c] = 0.f; sdx[c] = 0.f; }
+
+    stage(t0 - 1);
+    stage(t0);
+    for (int t = t0; t < t1; ++t) {
+        stage(t + 1);                                            // (slot of frame t - 2: its readers passed the barrier below)
+        __syncthreads();
+        float acc[SB_PPT][FOLD];
+#pragma unroll
+        for (int j = 0; j < SB_PPT; ++j)
+#pragma unroll
+            for (int c = 0; c < FOLD; ++c) acc[j][c] = 0.f;
+        // output position q = p - (k - 1): tap (kt, kh, kw) reads the entry at frame t + 1 - kt, row + 1 - kh, column + 1 - kw
+#pragma unroll 1
+        for (int r = 0; r < 9; ++r) {                            // (a real loop: unrolled, all 27 x FOLD weights are fetched at once and spill)
+            const int kt = r / 3, kh = r - kt * 3;
+            const f32x2* sl = ring + ((t + 4 - kt) % 3) * slot + (1 - kh) * W2 + 1;
+            const float* wr = w3d + r * 3;
+            f32x2 dp[SB_PPT][3];
+#pragma unroll
+            for (int j = 0; j < SB_PPT; ++j)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) dp[j][kw] = sl[pent[j] - kw];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int c = 0; c < FOLD; ++c) {
+                    const float wv = wr[c * 27 + kw];            // [2][HALF][27] flat = [FOLD][27]: wave-uniform
+#pragma unroll
+                    for (int j = 0; j < SB_PPT; ++j) acc[j][c] += wv * (c < HALF ? dp[j][kw][0] : dp[j][kw][1]);
+                }
+            }
+        }
+        const long fbase = ((long)b * T + t) * plane;
+#pragma unroll
+        for (int j = 0; j < SB_PPT; ++j) {
+            const long m = fbase + (poff[j] >= 0 ? poff[j] : 0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                float x[8], o[8];
+                load8b(Xc + m * FOLD + ch * 8, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = ch * 8 + e;
+                    o[e] = (x[e] * scale[c] + shift[c] > 0.f) ? acc[j][c] : 0.f;
+                }
+                const bf16x8 ob = pack8(o);
+                if (poff[j] >= 0) {
+                    *reinterpret_cast<bf16x8*>(dxbn + m * FOLD + ch * 8) = ob;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float r = (float)ob[e]; sdy[ch * 8 + e] += r; sdx[ch * 8 + e] += r * x[e]; }
+                }
+            }
+        }
+        __syncthreads();                                         // the slot of frame t - 1 is overwritten next
+    }
+    // sums: lanes -> wave (shuffles) -> workgroup (LDS) -> memory
+#pragma unroll
+    for (int c = 0; c < FOLD; ++c) {
+        float a = sdy[c], d = sdx[c];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); d += __shfl_xor(d, m, 64); }
+        sdy[c] = a; sdx[c] = d;
+    }
+    STES_DET_WAVES(det, if ((tid & 63) == 0) {
+        _Pragma("unroll") for (int c = 0; c < FOLD; ++c) { atomicAdd(&red[c], sdy[c]); atomicAdd(&red[FOLD + c], sdx[c]); }
+    });
+    __syncthreads();
+    det_enter(det);
+    if (tid < 2 * FOLD) atomicAdd((tid < FOLD ? s_dy : s_dyr) + (tid < FOLD ? tid : tid - FOLD), red[tid]);
+    det_leave(det);
+}
+
 }  // namespace
 
 int stes_gsm_small_forward(const uint16_t* Xc, const float* scale, const float* shift, const uint16_t* wt, const float* b3d, float* gate,
@@ -360,6 +486,34 @@ int stes_gsm_small_forward(const uint16_t* Xc, const float* scale, const float* 
     } while (0)
     if (fold == 8) SMALL_CASE(8); else SMALL_CASE(16);
 #undef SMALL_CASE
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+int stes_gsm_small_dxbn(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d, uint16_t* dxbn,
+                        float* s_dy, float* s_dyr, int B, int T, int H, int W, int fold, void* stream) {
+    STES_CHECK(fold == 8 || fold == 16, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: the narrow-slice kernel is built for fold 8 and 16");
+    STES_CHECK(W <= 256 * SB_PPT, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: image row too wide for the tile");
+    auto lds_of = [&](int th) { return (size_t)3 * (th + 2) * (W + 2) * 8 + 2 * fold * sizeof(float); };
+    int th = 256 * SB_PPT / W;
+    if (th > H) th = H;
+    while (th > 1 && lds_of(th) > 40 * 1024) --th;
+    const int rt = stes_div_up(H, th);
+    th = stes_div_up(H, rt);
+    // frames per segment: a segment stages two frames more than it produces; at least about four workgroups per compute unit
+    int tseg = T;
+    while (tseg > 8 && (long)rt * B * stes_div_up(T, tseg) < 1024) tseg = (tseg + 1) / 2;
+    SmallGeom gm;
+    gm.B = B; gm.T = T; gm.H = H; gm.W = W; gm.TH = th; gm.TSEG = tseg;
+    gm.fd_W = make_fastdiv(W); gm.fd_WN = make_fastdiv(W + 2);
+    const dim3 grid(rt, stes_div_up(T, tseg), B);
+    const StesDet det = stes_det_take(grid.x * grid.y * grid.z);
+    if (fold == 8)
+        hipLaunchKernelGGL(gsm_dxbn_small_kernel<8>, grid, dim3(256), lds_of(th), (hipStream_t)stream, dpre, (const bf16*)Xc, scale, shift, w3d,
+                           (bf16*)dxbn, s_dy, s_dyr, gm, det);
+    else
+        hipLaunchKernelGGL(gsm_dxbn_small_kernel<16>, grid, dim3(256), lds_of(th), (hipStream_t)stream, dpre, (const bf16*)Xc, scale, shift, w3d,
+                           (bf16*)dxbn, s_dy, s_dyr, gm, det);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

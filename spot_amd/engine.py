@@ -329,11 +329,11 @@ class Block:
             if fold >= 32:               # gate-conv backward in one kernel: dxbn, its BatchNorm3d sums, conv3D weight/bias gradient
                 lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), p(bng.s_dy),
                          p(bng.s_dyr), p(g(gs.conv3D.weight)), p(g(gs.conv3D.bias)), p(e.gsm_ws(fold)), C.byref(geom))
-            else:
+            else:                        # narrow slices: dxbn and its sums in one kernel, the conv3D gradients beside it
                 side(lambda: lib.call("stes_gsm_bwd_wgrad", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(g(gs.conv3D.weight)),
                                       p(g(gs.conv3D.bias)), C.byref(geom)))
-                lib.call("stes_gsm_dxbn", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), C.byref(geom))
-                lib.bn_bwd_reduce(dxbn, Xc, Mi, fold, [bng.s_dy, bng.s_dyr])
+                lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(bng.scale), p(bng.shift), p(gs.conv3D.weight), p(dxbn), p(bng.s_dy),
+                         p(bng.s_dyr), None, None, None, C.byref(geom))
             bng.bwd_finalize(Mi)
             dXf = sc("gsm.dXf", Mi * fold)
             lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(self.gate), p(dxbn), p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))

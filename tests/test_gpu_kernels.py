@@ -491,11 +491,11 @@ def _gsm_run(z, mode, fused=False):
         dw = torch.zeros_like(w3d); db = torch.zeros(2, device="cuda")
         dxbn = torch.empty(M, fold, dtype=BF, device="cuda")
         sd = torch.zeros(fold, device="cuda"); sdx = torch.zeros(fold, device="cuda")
-        if fused and fold >= 32:                                 # (narrower slices: one-kernel forward, backward kernel sequence)
-            ws = torch.zeros(lib.lib().stes_gsm_bwd_conv_ws_floats(fold), device="cuda")
+        if fused:                                                # (narrow slices take no workspace)
+            ws = torch.zeros(lib.lib().stes_gsm_bwd_conv_ws_floats(fold), device="cuda") if fold >= 32 else None
             lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn),
                      lib.ptr(sd), lib.ptr(sdx), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), C.byref(geom))
-            assert not bool(ws.any())
+            assert ws is None or not bool(ws.any())
         else:
             lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(dw), lib.ptr(db), C.byref(geom))
             lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(Xc), lib.ptr(scale), lib.ptr(shift), lib.ptr(w3d), lib.ptr(dxbn), C.byref(geom))
@@ -622,6 +622,27 @@ def test_gsm_narrow_slice_forward_in_one_kernel(B, T, H, W, fold):
     lib.call("stes_gsm_shift", lib.ptr(dXc), lib.ptr(gate), lib.ptr(G2), C.byref(geom))
     torch.cuda.synchronize()
     assert torch.equal(G.view(torch.int16), G2.view(torch.int16))
+    # backward of the gate conv: dxbn bit for bit (same products, the tap order of the sequence's kernel), the sums within fp32
+    # summation order, the conv3D gradients only when asked for
+    dpre = dev(torch.randn(M, 2, generator=g) * 0.1)
+    dsc, dsh, dw3d = dev(sc), dev(sh), dev(w3d)
+    dxa = torch.full((M, fold), 9.0, dtype=BF, device="cuda"); dxb = torch.full_like(dxa, 7.0)
+    sa = torch.zeros(2, fold, device="cuda"); sb = torch.zeros(2, fold, device="cuda")
+    dwa = torch.zeros(2, half, 27, device="cuda"); dba = torch.zeros(2, device="cuda"); dwb = torch.zeros_like(dwa); dbb = torch.zeros_like(dba)
+    lib.call("stes_gsm_dxbn", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw3d), lib.ptr(dxa), C.byref(geom))
+    lib.bn_bwd_reduce(dxa, dXc, M, fold, [sa[0], sa[1]])
+    lib.call("stes_gsm_bwd_wgrad", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dwa), lib.ptr(dba), C.byref(geom))
+    lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw3d), lib.ptr(dxb), lib.ptr(sb[0]), lib.ptr(sb[1]),
+             lib.ptr(dwb), lib.ptr(dbb), None, C.byref(geom))
+    torch.cuda.synchronize()
+    close(dxb.float().cpu(), dxa.float().cpu(), 1e-2, 1e-6)
+    assert float((sb - sa).norm() / (sa.norm() + 1e-12)) < 1e-4
+    assert torch.equal(dwa, dwb) or float((dwa - dwb).norm() / dwa.norm()) < 1e-5
+    sb.zero_(); dwb.zero_()
+    lib.call("stes_gsm_bwd_conv", lib.ptr(dpre), lib.ptr(dXc), lib.ptr(dsc), lib.ptr(dsh), lib.ptr(dw3d), lib.ptr(dxb), lib.ptr(sb[0]), lib.ptr(sb[1]),
+             None, None, None, C.byref(geom))
+    torch.cuda.synchronize()
+    assert float((sb - sa).norm() / (sa.norm() + 1e-12)) < 1e-4 and not bool(dwb.any())
 
 
 @pytest.mark.parametrize("fold", [8, 16, 32, 80, 192])
@@ -631,7 +652,7 @@ def test_gsm_vs_reference_golden(golden, fold, mode, fused):
     """Inputs of the golden vectors rounded to bf16 (the kernels' storage type); expected values are the
     reference's fp32 outputs -> tolerance 2 bf16 ulp + the input rounding + the gate conv weights rounded to bf16 (like
     every other conv weight on the path; up to 2592 products per gate value at fold 192).  fused: the one-kernel forward and
-    (from fold 32 up) the one-kernel gate-conv backward."""
+    the one-kernel gate-conv backward."""
     z = golden(f"gsm_f{fold}_{mode}_rand")
     r = _gsm_run(z, mode, fused)
     close(r["y"], torch.from_numpy(z["y"]), 2e-2, 5e-2)

@@ -81,5 +81,7 @@ for (B, T, H, W, fold, n_blocks) in SHAPES:
         run("bwd_wgrad + dxbn + reduce", old_bwd, 2 * unit)
         run("gsm_bwd_conv", lambda: lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(sc), p(sh), p(w3d), p(dxbn), p(sd), p(sdx), p(dw), p(db),
                                              p(ws), C.byref(geom)), 2 * unit)
+        run("gsm_bwd_conv without conv3D grads", lambda: lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(sc), p(sh), p(w3d), p(dxbn), p(sd), p(sdx), None,
+                                                                  None, None, C.byref(geom)), 2 * unit)
         run("gsm_bwd_conv, no workspace", lambda: lib.call("stes_gsm_bwd_conv", p(dpre), p(Xc), p(sc), p(sh), p(w3d), p(dxbn), p(sd), p(sdx),
                                                            p(dw), p(db), None, C.byref(geom)), 2 * unit)
