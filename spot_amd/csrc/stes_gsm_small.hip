@@ -327,9 +327,7 @@ __global__ __launch_bounds__(256) void gsm_fwd_small_kernel(const bf16* __restri
 // nine (frame, row) tap rows are the outer loop, so that a tap row's 3 x FOLD weights (wave-uniform: scalar registers) are
 // fetched once per frame and workgroup instead of once per position.  The sums stay in registers over the whole segment and
 // leave through one atomic per channel and workgroup.
-constexpr int SB_PPT = 4;        // positions per thread
-
-template <int FOLD>
+template <int FOLD, int SB_PPT>   // SB_PPT: positions per thread (its accumulators are SB_PPT x FOLD registers)
 __global__ __launch_bounds__(256) void gsm_dxbn_small_kernel(const float* __restrict__ dpre, const bf16* __restrict__ Xc,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ w3d, bf16* __restrict__ dxbn, float* s_dy,
@@ -492,7 +490,9 @@ int stes_gsm_small_forward(const uint16_t* Xc, const float* scale, const float* 
 
 int stes_gsm_small_dxbn(const float* dpre, const uint16_t* Xc, const float* scale, const float* shift, const float* w3d, uint16_t* dxbn,
                         float* s_dy, float* s_dyr, int B, int T, int H, int W, int fold, void* stream) {
+    // (32 channels: accumulators and sums of two positions already fill the register file -- one wave per SIMD)
     STES_CHECK(fold == 8 || fold == 16, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: the narrow-slice kernel is built for fold 8 and 16");
+    const int SB_PPT = 4;
     STES_CHECK(W <= 256 * SB_PPT, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: image row too wide for the tile");
     auto lds_of = [&](int th) { return (size_t)3 * (th + 2) * (W + 2) * 8 + 2 * fold * sizeof(float); };
     int th = 256 * SB_PPT / W;
@@ -508,12 +508,10 @@ int stes_gsm_small_dxbn(const float* dpre, const uint16_t* Xc, const float* scal
     gm.fd_W = make_fastdiv(W); gm.fd_WN = make_fastdiv(W + 2);
     const dim3 grid(rt, stes_div_up(T, tseg), B);
     const StesDet det = stes_det_take(grid.x * grid.y * grid.z);
-    if (fold == 8)
-        hipLaunchKernelGGL(gsm_dxbn_small_kernel<8>, grid, dim3(256), lds_of(th), (hipStream_t)stream, dpre, (const bf16*)Xc, scale, shift, w3d,
-                           (bf16*)dxbn, s_dy, s_dyr, gm, det);
-    else
-        hipLaunchKernelGGL(gsm_dxbn_small_kernel<16>, grid, dim3(256), lds_of(th), (hipStream_t)stream, dpre, (const bf16*)Xc, scale, shift, w3d,
-                           (bf16*)dxbn, s_dy, s_dyr, gm, det);
+#define DXBN_CASE(F, P) hipLaunchKernelGGL((gsm_dxbn_small_kernel<F, P>), grid, dim3(256), lds_of(th), (hipStream_t)stream, dpre, (const bf16*)Xc, \
+                                          scale, shift, w3d, (bf16*)dxbn, s_dy, s_dyr, gm, det)
+    if (fold == 8) DXBN_CASE(8, 4); else DXBN_CASE(16, 4);
+#undef DXBN_CASE
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
