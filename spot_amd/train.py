@@ -27,6 +27,7 @@ torch.optim.AdamW's format in both modes, so a run can be resumed in the other o
 from __future__ import annotations
 
 import argparse
+import random
 import glob
 import json
 import os
@@ -65,6 +66,8 @@ def get_args(argv=None):
     p.add_argument("--num_classes", type=int, default=None, help="event classes (without background) when data/<dataset>/class.txt is absent")
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--fused", action="store_true", help="HIP loss + backward + AdamW (implied under torchrun)")
+    p.add_argument("--mixup", action="store_true", help="the reference loader's mixup (dataset/frame.py:338-353; train_e2e_spatial.py:141); "
+                   "soft labels: not with --fused or --predict_location")
     p.add_argument("--augment", action="store_true",
                    help="the reference loader's random augmentation (dataset/frame.py:78-140) on the GPU; shards may then hold "
                         "frames of any size (validation clips are resized to crop_dim)")
@@ -139,11 +142,53 @@ class AugmentedClips:
             yield {**batch, "frame": frame, "xy": xy}
 
 
+class MixupClips:
+    """Mixup of the reference's training loader (dataset/frame.py:338-353) on whole batches: every clip is blended with a second
+    clip (here: its neighbour in the batch, where the reference draws another clip from the dataset) with a weight
+    l ~ Beta(0.2, 0.2); `label` becomes the [T, num_classes] distribution (num_classes counts the background class) l * onehot(a) + (1 - l) * onehot(b), `frame` the
+    same blend of the two normalised clips, `contains_event` the larger of the two, `xy` stays the first clip's.
+    As in the reference the soft labels only go through the classification loss: its location loss masks with `label != 0`
+    on hard labels (train_e2e_spatial.py:582), so mixup and --predict_location do not combine there either."""
+
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # dataset/frame.py:124 on frames scaled by :29
+
+    def __init__(self, loader, num_classes, seed):
+        self.loader, self.nc, self.rng = loader, num_classes, random.Random(seed)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def normalised(self, frame):
+        if frame.dtype != torch.uint8:
+            return frame.float()
+        shape = (1, 1, -1, 1, 1)
+        mean = torch.tensor(self.MEAN[:frame.shape[2]], device=frame.device).view(shape)
+        std = torch.tensor(self.STD[:frame.shape[2]], device=frame.device).view(shape)
+        return (frame.float() / 255 - mean) / std
+
+    def __iter__(self):
+        for batch in self.loader:
+            frame, label = self.normalised(batch["frame"]), batch["label"]
+            B, T = label.shape
+            lam = torch.tensor([self.rng.betavariate(0.2, 0.2) for _ in range(B)], dtype=torch.float32)
+            other = torch.roll(torch.arange(B), 1)
+            dist = torch.zeros(B, T, self.nc)
+            dist.scatter_(2, label.unsqueeze(-1), lam.view(B, 1, 1).expand(B, T, 1))
+            dist.scatter_add_(2, label[other].unsqueeze(-1), (1.0 - lam).view(B, 1, 1).expand(B, T, 1))
+            lf = lam.to(frame.device).view(B, 1, 1, 1, 1)
+            out = {**batch, "frame": lf * frame + (1.0 - lf) * frame[other.to(frame.device)], "label": dist}
+            ce = batch.get("contains_event", (label.sum(1) > 0).long())
+            out["contains_event"] = torch.maximum(ce, ce[other])
+            yield out
+
+
 def get_loaders(args, num_classes, rank=0, world=1):
     tr, va = _get_loaders(args, num_classes, rank, world)
     if getattr(args, "augment", False):
         tr = AugmentedClips(tr, args.device, args.crop_dim, False, 1000 + rank)
         va = AugmentedClips(va, args.device, args.crop_dim, True, 0)
+    if getattr(args, "mixup", False):
+        tr = MixupClips(tr, num_classes, 2000 + rank)
     return tr, va
 
 
@@ -339,6 +384,9 @@ def main(args):
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if fused and args.acc_grad_iter != 1:
         raise NotImplementedError("--fused takes the whole per-GPU batch in one step (acc_grad_iter 1)")
+    if getattr(args, "mixup", False) and (fused or args.predict_location):
+        raise NotImplementedError("--mixup gives soft labels: the fused step and the location loss take class indices "
+                                  "(the reference's location loss fails on them too, train_e2e_spatial.py:582-591)")
     classes = load_classes(args)
     model = E2EModel(len(classes) + 1, args.feature_arch, args.temporal_arch, clip_len=args.clip_len, modality=args.modality,
                      device=args.device, predict_location=args.predict_location, pred_loc_arch=args.pred_loc_arch,

@@ -400,3 +400,30 @@ def test_optimizer_file_scaler_state_loads_into_an_enabled_grad_scaler():
     enabled.load_state_dict(sd)
     assert enabled.state_dict()["scale"] == 65536.0
     assert TR.scaler_state(enabled) == enabled.state_dict() and TR.scaler_state(None) == sd
+
+
+def test_mixup_loader_follows_the_reference_recipe():
+    """reference dataset/frame.py:338-353: label distribution l * onehot(a) + (1 - l) * onehot(b), frames blended with the same
+    weight after normalisation, contains_event the larger of the two, xy the first clip's; l ~ Beta(0.2, 0.2) from `random`."""
+    import random
+    from spot_amd.train import MixupClips
+    g = torch.Generator().manual_seed(3)
+    B, T, nc = 3, 5, 6
+    batch = {"frame": torch.randint(0, 256, (B, T, 3, 4, 4), generator=g, dtype=torch.uint8),
+             "label": torch.tensor([[0, 2, 0, 0, 5], [0, 0, 0, 0, 0], [1, 1, 0, 3, 0]]), "xy": torch.rand(B, T, 2, generator=g)}
+    out = next(iter(MixupClips([batch], nc + 1, seed=11)))        # (the model's class count: events + background)
+    rng = random.Random(11)
+    lam = [rng.betavariate(0.2, 0.2) for _ in range(B)]
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    norm = (batch["frame"].float() / 255 - mean) / std
+    for i in range(B):
+        j = (i - 1) % B                                           # the neighbour clip
+        want = np.zeros((T, nc + 1))                              # the reference's own lines
+        want[range(T), batch["label"][i].numpy()] = lam[i]
+        want[range(T), batch["label"][j].numpy()] += 1.0 - lam[i]
+        np.testing.assert_allclose(out["label"][i].numpy(), want, atol=1e-6)
+        np.testing.assert_allclose(out["frame"][i].numpy(), (lam[i] * norm[i] + (1.0 - lam[i]) * norm[j]).numpy(), atol=1e-5)
+    assert torch.allclose(out["label"].sum(-1), torch.ones(B, T), atol=1e-6)
+    assert out["contains_event"].tolist() == [1, 1, 1] and torch.equal(out["xy"], batch["xy"])
+    # the label layout E2EModel.epoch flattens for the soft-label cross entropy (train_e2e_spatial.py:546-550)
+    assert out["label"].view(-1, out["label"].shape[-1]).shape == (B * T, nc + 1)
