@@ -606,6 +606,33 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const stes_cast_de
     }
     const stes_cast_desc d = table[lo];
     const long total = (long)d.dst_rows * d.ld;
+    if (d.transpose) {
+        // Transposed copies go through LDS in tiles of 32 destination rows x 64 destination columns, so that the source is read in
+        // 128-byte runs (element-wise, a wave read 64 source rows for 4 bytes each: 28x the bytes of the whole table).  The entry's
+        // workgroups share its tiles round-robin.
+        __shared__ float tile[64][33];
+        const int nb = (int)((total + STES_CAST_CHUNK - 1) / STES_CAST_CHUNK);
+        const int tr = (d.dst_rows + 31) >> 5, tc = (d.ld + 63) >> 6;
+        for (int t = (int)blockIdx.x - d.block0; t < tr * tc; t += nb) {
+            const int r0 = (t / tc) << 5, c0 = (t - (t / tc) * tc) << 6;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = k * 256 + threadIdx.x, sr = idx >> 5, sc = idx & 31;
+                const int dcol = c0 + sr, drow = r0 + sc;            // source row = destination column
+                float v = 0.f;
+                if (dcol < d.rows && drow < d.cols) v = d.src[(long)dcol * d.cols + (drow < d.perm_fold ? gsm_dest(drow, d.perm_fold) : drow)];
+                tile[sr][sc] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = k * 256 + threadIdx.x, dr = idx >> 6, dc = idx & 63;
+                if (r0 + dr < d.dst_rows && c0 + dc < d.ld) reinterpret_cast<bf16*>(d.dst)[(long)(r0 + dr) * d.ld + c0 + dc] = (bf16)tile[dc][dr];
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < STES_CAST_CHUNK / 256; ++j) {
         const long i = (long)(blockIdx.x - d.block0) * STES_CAST_CHUNK + j * 256 + threadIdx.x;

@@ -946,7 +946,8 @@ def test_cast_bf16_multi_equals_single_launches():
     from spot_amd import lib
     g = torch.Generator().manual_seed(77)
     cases = [(40, 24, 24, 40, 0, 0), (40, 24, 40, 24, 1, 0), (33, 27, 32, 40, 0, 0), (64, 96, 96, 64, 0, 16), (64, 96, 64, 96, 1, 16),
-             (7, 768, 768, 8, 0, 0), (7, 768, 8, 768, 1, 0), (300, 24, 24, 300, 0, 0), (300, 24, 304, 24, 1, 0)]     # (the last two: several chunks)
+             (7, 768, 768, 8, 0, 0), (7, 768, 8, 768, 1, 0), (300, 24, 24, 300, 0, 0), (300, 24, 304, 24, 1, 0),     # (the last two: several chunks)
+             (320, 768, 320, 768, 1, 80), (2304, 770, 2304, 776, 1, 0), (100, 90, 104, 90, 1, 0)]                    # (many tiles, ragged on both sides)
     srcs = [dev(torch.randn(r, c, generator=g)) for r, c, *_ in cases]
     single = [torch.full((dr * ld,), 3.0, dtype=BF, device="cuda") for _, _, ld, dr, _, _ in cases]
     multi = [torch.full((dr * ld,), 4.0, dtype=BF, device="cuda") for _, _, ld, dr, _, _ in cases]

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Evidence run of a round on the GPU box (every step under its own time limit; stops at the first failure):
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r2'
-# then, back here:  python tools/refresh_profiles.py r2
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r3'
+# then, back here:  python tools/refresh_profiles.py r3
 set -e -o pipefail
-tag=${1:-r2}
+tag=${1:-r3}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
+B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- python3 $B > $out/prof.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_serial -o ${tag}s -- python3 $B --serial > $out/prof_serial.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --serial > $out/pmc_fetch.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --serial > $out/pmc_write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs --serial > $out/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o $tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs --serial > $out/pmc_write.log 2>&1
 # the trace files are large and not needed back (only the stats and the counter tables)
 rm -f $out/prof/*_kernel_trace.csv $out/prof_serial/*_kernel_trace.csv
 # the bench lines read the dominant kernel's HBM traffic from profiles/pmc_traffic.json: rebuild it from the passes above first

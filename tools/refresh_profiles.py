@@ -2,7 +2,7 @@
 """Rebuild the round's files under profiles/ from the rocprofv3 output a GPU run left under gpurun_out/<tag>/ (tools/profile_round.sh):
 prof (the step as benchmarked), prof_serial (--serial), pmc_fetch / pmc_write (counter passes of the --serial command), bench*.json.
 
-    python tools/refresh_profiles.py r2
+    python tools/refresh_profiles.py r3
 """
 import json
 import os
@@ -10,7 +10,7 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(root)
 src = f"gpurun_out/{tag}"
@@ -33,7 +33,7 @@ with open("profiles/pmc_traffic.json", "w") as fp:
     subprocess.run([sys.executable, "tools/pmc_traffic.py", f"{src}/pmc_fetch/{tag}_counter_collection.csv",
                     f"{src}/pmc_write/{tag}_counter_collection.csv"], stdout=fp, check=True)
 tr = json.load(open("profiles/pmc_traffic.json")).get(r["kernel"], {})
-cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
+cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
 note_s = (f"Command: `{cmd} --serial` ({STEPS} steps traced). This is the mode bench.py's roofline pass measures in (each kernel alone on "
           f"the GPU): its HIP-event average for the dominant kernel `{r['kernel']}` was {r['avg_launch_us']:.1f} us per launch (this "
           f"trace: the row below). HBM traffic of every kernel from counter passes of the same --serial command: "
