@@ -11,7 +11,10 @@
  *  - `stream` is a hipStream_t passed as void*; launches are asynchronous;
  *  - return 0 on success, a negative STES_ERR_* otherwise (text via stes_last_error);
  *  - activations are NHWC ("channels last") bf16, viewed as [rows = n*h*w][channels];
- *  - bf16 values are passed as raw 16-bit words (uint16_t).
+ *  - bf16 values are passed as raw 16-bit words (uint16_t);
+ *  - one device per process: occupancy figures and the raised dynamic-LDS limits of the kernels are looked up once, on
+ *    the device that is current at a kernel's first launch (the one exception, stes_gru_forward_noalloc, keeps its
+ *    scratch address per device).  Drive a second GPU from a second process.
  */
 #ifndef STES_H
 #define STES_H
