@@ -28,6 +28,34 @@ __device__ __forceinline__ int frame_of(uint32_t m, const Geom& gm) {
     return (int)(f - fdiv(f, gm.fd_T) * gm.T);
 }
 
+// Workgroup -> (row tile, frame, clip) for the kernels that read a frame's two neighbours: consecutive workgroups go round-robin
+// over the 8 XCDs, so with frames as the fast index the three readers of a frame sat on three XCDs and every L2 fetched it
+// again.  Here a clip belongs to XCD (clip mod 8) and the frames of a clip follow each other on that XCD.  Launch
+// 8 * ceil(B / 8) * T * row_tiles workgroups; false: no work for this one.
+__device__ __forceinline__ bool xcd_clip_map(int row_tiles, int T, int B, int& rt, int& t, int& b) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per_clip = T * row_tiles;
+    const int cl = j / per_clip, rem = j - cl * per_clip;
+    b = xcd + 8 * cl;
+    t = rem / row_tiles;
+    rt = rem - t * row_tiles;
+    return b < B;
+}
+
+// The same idea for the elementwise kernels that read a row's neighbour one frame away: with clips a multiple of 8 (and a
+// grid that is one), XCD x walks the clips x, x + 8, ... whole, so a frame and its neighbours pass through one L2.  `body(i)`
+// gets the flat element index either way.
+template <class F>
+__device__ __forceinline__ void gsm_flat_walk(uint32_t total, uint32_t per_clip, int B, F&& body) {
+    if ((B & 7) == 0 && (gridDim.x & 7) == 0) {
+        const uint32_t xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+        for (uint32_t b = xcd; b < (uint32_t)B; b += 8)
+            for (uint32_t i = jb * 256 + threadIdx.x; i < per_clip; i += nbx * 256) body(b * per_clip + i);
+    } else {
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) body(i);
+    }
+}
+
 __device__ __forceinline__ int dest_of(int c, int fold) {
     const int half = fold >> 1, quarter = fold >> 2;
     const int g = c / half, rem = c - g * half;
@@ -206,7 +234,7 @@ __global__ __launch_bounds__(256) void gsm_shift_kernel(const bf16* __restrict__
     const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
     const uint32_t total = (uint32_t)(gm.M * nch);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    gsm_flat_walk(total, (uint32_t)(gm.T * plane * nch), gm.B, [&](uint32_t i) {
         uint32_t mu, chk;
         fdivmod(i, gm.fd_nch, mu, chk);
         const long m = mu; const int c0 = (int)chk * V;
@@ -230,7 +258,7 @@ __global__ __launch_bounds__(256) void gsm_shift_kernel(const bf16* __restrict__
             o[k] = (bf16)(ys + r);
         }
         *reinterpret_cast<vecb*>(G + m * fold + c0) = o;
-    }
+    });
 }
 
 // ------------------------------------------------------------------ backward: gate pre-activation gradient
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restric
     const int fold = gm.fold, half = fold >> 1;
     const long plane = (long)gm.H * gm.W;
     const uint32_t total = (uint32_t)(gm.M * 2);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    gsm_flat_walk(total, (uint32_t)(gm.T * plane * 2), gm.B, [&](uint32_t i) {
         const long m = i >> 1; const int g = (int)(i & 1);
         const int t = frame_of(i >> 1, gm);
         const int tp = g == 0 ? t - 1 : t + 1;                 // frame whose output used y[t]
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_kernel(const bf16* __restric
         }
         const float gt = gate[i];
         dpre[i] = acc * (1.f - gt * gt);
-    }
+    });
 }
 
 // The same for groups of 16 channels and more (half % 8 == 0, half >= 16): thread per 16-byte chunk, so that a wave's loads are
@@ -280,7 +308,13 @@ __global__ __launch_bounds__(256) void gsm_bwd_gate_rows_kernel(const bf16* __re
     fdivmod((uint32_t)threadIdx.x, fd_nch, r, ch);
     const bool active = (int)r < rows_per_block;
     const int g = (int)ch >= hch;
-    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    // (row blocks in XCD-local clip order where the shapes allow it: see gsm_flat_walk)
+    const long bpc = (long)gm.T * plane / rows_per_block;                   // row blocks per clip
+    const bool by_xcd = (gm.B & 7) == 0 && (gridDim.x & 7) == 0 && bpc * rows_per_block == (long)gm.T * plane;
+    const long nbx = gridDim.x >> 3, per_xcd = by_xcd ? (gm.B >> 3) * bpc : 0;
+    const long first = by_xcd ? (long)(blockIdx.x >> 3) : (long)blockIdx.x, last = by_xcd ? per_xcd : n_blocks, step = by_xcd ? nbx : (long)gridDim.x;
+    for (long it = first; it < last; it += step) {
+        const long blk = by_xcd ? ((blockIdx.x & 7) + 8 * (it / bpc)) * bpc + it % bpc : it;
         const long m = blk * rows_per_block + r;
         float acc = 0.f;
         if (active && m < gm.M) {
@@ -603,7 +637,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict_
     const int fold = gm.fold, half = fold >> 1, nch = fold / V;
     const long plane = (long)gm.H * gm.W;
     const uint32_t total = (uint32_t)(gm.M * nch);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    gsm_flat_walk(total, (uint32_t)(gm.T * plane * nch), gm.B, [&](uint32_t i) {
         uint32_t mu, chk;
         fdivmod(i, gm.fd_nch, mu, chk);
         const long m = mu; const int c0 = (int)chk * V;
@@ -626,7 +660,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_dx_kernel(const bf16* __restrict_
             o[k] = (bf16)(dr + dyt * gt + alpha[c0 + k] * (float)db[k] + beta[c0 + k] * (float)x[k] + delta[c0 + k]);
         }
         *reinterpret_cast<vecb*>(dXf + m * fold + c0) = o;
-    }
+    });
 }
 
 // ------------------------------------------------------------------ forward in one kernel (fold >= 32): gate conv on MFMA + shift
@@ -649,7 +683,9 @@ __global__ __launch_bounds__(256) void gsm_fwd_fused_kernel(const bf16* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
     const int W = gm.W, H = gm.H, T = gm.T, ZW = W + 2, TH = ft.TH, ZPp = ft.ZPp;
-    const int h0 = blockIdx.x * TH, t = blockIdx.y, b = blockIdx.z;
+    int rtile, t, b;
+    if (!xcd_clip_map((H + TH - 1) / TH, T, gm.B, rtile, t, b)) return;
+    const int h0 = rtile * TH;
     const int NP = TH * W, PH = (TH + 2) * W;
     float* zbuf = reinterpret_cast<float*>(smem);         // [2 targets][16 taps][ZPp]
     float* gl = zbuf + 32 * ZPp;                           // [group][target][NP]: gates of (t, g) and of the group's neighbour frame
@@ -830,7 +866,9 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
     constexpr int SA = 96;                                 // Ag row stride (bytes): 32 taps + 16 pad, an odd multiple of 32
     const int fold = gm.fold, half = fold >> 1, nch = fold >> 3;
     const int W = gm.W, H = gm.H, T = gm.T, ZW = W + 2, TH = bt.TH, rows = TH + 2, NPp = bt.NPp, SX = bt.SX;
-    const int h0 = blockIdx.x * TH, t = blockIdx.y, b = blockIdx.z;
+    int rtile, t, b;
+    if (!xcd_clip_map((H + TH - 1) / TH, T, gm.B, rtile, t, b)) { det_enter(det); det_leave(det); return; }   // (deterministic mode: the turn still passes)
+    const int h0 = rtile * TH;
     const int NP = TH * W;
     unsigned char* xt = smem;                                                  // [NPp][SX] (+64 slack)
     unsigned char* ag = xt + (size_t)NPp * SX + 64;                            // [NPp][SA]
@@ -1055,7 +1093,7 @@ __global__ __launch_bounds__(256) void gsm_bwd_conv_kernel(const float* __restri
     const int nws = fold * 27 + 2 * fold + 2;
     det_enter(det);
     if (ws) {
-        float* rep = ws + (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % n_rep * nws;
+        float* rep = ws + (size_t)(blockIdx.x % n_rep) * nws;
         for (int i = tid; i < nws; i += 256) atomicAdd(rep + i, red[i]);
     } else {
         for (int i = tid; i < fold * 27; i += 256) atomicAdd(dw + i, red[i]);
@@ -1386,7 +1424,7 @@ extern "C" int stes_gsm_forward(const uint16_t* Xc, const float* scale, const fl
     ft.fd_W = make_fastdiv(gm.W); ft.fd_nch = make_fastdiv(gm.fold / 8);
     const size_t lds = ((size_t)32 * ft.ZPp + 4 * ft.TH * gm.W + 2 * gm.fold) * sizeof(float);
     STES_CHECK(lds <= 64 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_forward: image row too wide for the LDS tile");
-    const dim3 grid(stes_div_up(gm.H, ft.TH), gm.T, gm.B);
+    const dim3 grid(8 * stes_div_up(gm.B, 8) * gm.T * stes_div_up(gm.H, ft.TH));       // (see xcd_clip_map)
     const int ks = (gm.fold / 2 + 31) / 32;
 #define FWD_CASE(K) hipLaunchKernelGGL((gsm_fwd_fused_kernel<K>), grid, dim3(256), lds, S(stream), (const bf16*)Xc, scale, shift, (const bf16*)wt, b3d, gate, (bf16*)G, gm, ft)
     if (ks == 1) FWD_CASE(1); else if (ks == 2) FWD_CASE(2); else FWD_CASE(3);
@@ -1420,7 +1458,7 @@ extern "C" int stes_gsm_bwd_conv(const float* dpre, const uint16_t* Xc, const fl
     const size_t lds = (size_t)bt.NPp * bt.SX + 64 + (size_t)bt.NPp * 96 + (size_t)gm.fold * 64 +
                        ((size_t)3 * (bt.TH + 2) * (gm.W + 2) * 2 + gm.fold * 27 + 12 * gm.fold + 2) * sizeof(float);
     STES_CHECK(lds <= 160 * 1024, STES_ERR_UNSUPPORTED, "stes_gsm_bwd_conv: tile does not fit LDS");
-    const dim3 grid(stes_div_up(gm.H, bt.TH), gm.T, gm.B);
+    const dim3 grid(8 * stes_div_up(gm.B, 8) * gm.T * stes_div_up(gm.H, bt.TH));      // (see xcd_clip_map)
     const int nct = (gm.fold / 2 + 15) / 16;
 #define BWD_CASE(N)                                                                                                                \
     do {                                                                                                                           \
