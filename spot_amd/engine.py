@@ -406,6 +406,7 @@ class Engine:
         self.casts, self.packs, self.gsm_preps = [], [], []
         self.input_mean, self.input_std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)   # uint8 input only
         self.side = torch.cuda.Stream(device=dev)      # weight-gradient kernels (see Block.backward)
+        self.comm = torch.cuda.Stream(device=dev)      # hands finished gradient buckets to the all-reduce (see backward)
         self.side_done = [None, None]
         self._stats = torch.zeros(self.STATS_FLOATS, device=dev)
         self._stats_used = 0
@@ -943,8 +944,12 @@ class Engine:
         for blk in reversed(self.blocks):
             dZ = blk.backward(dZ, sums_done=blk is not self.blocks[-1])
             if on_ready and blk.name in ("s4.b1", "s3.b1"):
-                main.wait_stream(self.side)          # the bucket's weight gradients are complete
-                on_ready(*self.buckets[blk.name[:2]])
+                # The bucket is final once BOTH streams have passed this point.  The reduction is handed over from a third
+                # stream that waits for the two, so the input-gradient chain does not stall behind the queued weight gradients.
+                self.comm.wait_stream(main)
+                self.comm.wait_stream(self.side)
+                with torch.cuda.stream(self.comm):
+                    on_ready(*self.buckets[blk.name[:2]])
         # stem: dZ is masked by (X0 > 0) already and its sums against c0 were taken by s1.b1's backward
         bn0 = self.bn0
         bn0.bwd_finalize(self.M0)
