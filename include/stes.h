@@ -96,6 +96,25 @@ typedef struct {
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
+/* Two chained small products in one launch, for the squeeze-excite block's pair of 1x1 convolutions on the pooled vectors
+ * (timm SEModule fc1 -> ReLU -> fc2 -> sigmoid as the reference builds it, train_e2e_spatial.py:305-314) and their
+ * input-gradient pair in backward:
+ *   H[M,N1] = act1(A[M,K1] W1[N1,K1]^T + bias1), zeroed where relu_mask1 <= 0     (bf16, also written to memory)
+ *   C[M,N2] = act2(H W2[N2,N1]^T + bias2) * out_scale                             (fp32 or bf16)
+ * act: 0 none, 1 ReLU, 2 sigmoid.  A workgroup owns 16 rows of both products, H stays in LDS in between; the same
+ * roundings as two stes_gemm calls (H is rounded to bf16 before the second product).
+ * K1, N1 multiples of 8; N1 <= 256, K1 <= 1024, N2 <= 1024.  Replaces two launches of a few microseconds each that sit in a
+ * dependent chain between two large kernels of every block. */
+typedef struct {
+    const uint16_t* A; int64_t lda; int64_t M; int32_t K1;
+    const uint16_t* W1; int32_t ldw1; int32_t N1; const float* bias1; int32_t act1;
+    const uint16_t* relu_mask1; int64_t ldmask1;
+    uint16_t* H; int64_t ldh;
+    const uint16_t* W2; int32_t ldw2; int32_t N2; const float* bias2; int32_t act2; float out_scale;
+    void* C; int64_t ldc; int32_t c_f32;
+} stes_gemm2_args;
+int stes_gemm_small2(const stes_gemm2_args* a, void* stream);
+
 /* dW[N1,N2] += P[M,N1]^T * pro(Q)[M,N2]   (f32 atomics; caller zeroes dW)
  * dbias[N1] += column sums of P (optional; of the prologue's result when P has one).  pro() and the row mapping apply to Q only.
  * Replaces: autograd weight gradients of the same layers.                               */

@@ -428,6 +428,129 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const stes_gemm_args p)
     }
 }
 
+// ------------------------------------------------------------------ two chained small GEMMs (squeeze-excite FC pair)
+// Workgroup = 16 rows of both products.  Product 1: the four waves take the column fragments of H round-robin, each over the
+// whole K1, operands straight from global memory in MFMA layout (the weight rows as the A operand, so a lane ends up with four
+// consecutive columns of one row); H goes to memory and, as bf16, to LDS.  Product 2 reads H from LDS and W2 from memory the
+// same way.  Every wave's loads of a pass are in flight together; no cross-wave reduction.
+__device__ __forceinline__ float small_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_small2_kernel(const stes_gemm2_args p) {
+    constexpr int HS = 256 + 8;                                   // LDS row stride of H (elements): 16-byte rows, bank-shifted
+    __shared__ __attribute__((aligned(16))) bf16 Hs[16 * HS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long m0 = (long)blockIdx.x * 16, m = m0 + fr;
+    const bool row_ok = m < p.M;
+    const bf16* __restrict__ arow = (const bf16*)p.A + (row_ok ? m : 0) * p.lda;
+    // zero padding of H up to a multiple of 32 columns (the second product's k-steps)
+    const int n1p = (p.N1 + 31) & ~31;
+    for (int i = threadIdx.x; i < 16 * (n1p - p.N1); i += 256) Hs[(i / (n1p - p.N1)) * HS + p.N1 + i % (n1p - p.N1)] = (bf16)0.f;
+    // ---- product 1
+    const int nf1 = (p.N1 + 15) >> 4, nk1 = (p.K1 + 31) >> 5;
+    for (int f = wave; f < nf1; f += 4) {
+        const int n = f * 16 + fr;
+        const bf16* __restrict__ wrow = (const bf16*)p.W1 + (long)(n < p.N1 ? n : 0) * p.ldw1;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks0 = 0; ks0 < nk1; ks0 += 8) {
+            bf16x8 fa[8], fb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = (ks0 + u) * 32 + fq * 8;
+                const bool on = k < p.K1;                           // K1 is a multiple of 8: a chunk is inside or outside as a whole
+                fa[u] = (on && row_ok) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8();
+                fb[u] = (on && n < p.N1) ? *reinterpret_cast<const bf16x8*>(wrow + k) : zero8();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[u], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[u], acc0, 0, 0, 0);
+            }
+        }
+        // lane holds columns nb..nb+3 of row m
+        const int nb = f * 16 + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc0[r] + acc1[r];
+            if (p.bias1 && nb + r < p.N1) v += p.bias1[nb + r];
+            v = small_act(v, p.act1);
+            if (p.relu_mask1 && row_ok && nb + r < p.N1 && !((float)((const bf16*)p.relu_mask1)[m * p.ldmask1 + nb + r] > 0.f)) v = 0.f;
+            o[r] = (bf16)((nb + r < p.N1) ? v : 0.f);
+        }
+        *reinterpret_cast<bf16x4*>(&Hs[fr * HS + nb]) = o;
+        if (row_ok && p.H) {
+            bf16* h = (bf16*)p.H + m * p.ldh + nb;
+            if (nb + 3 < p.N1 && (p.ldh & 3) == 0) *reinterpret_cast<bf16x4*>(h) = o;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < p.N1) h[r] = o[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- product 2
+    const int nf2 = (p.N2 + 15) >> 4, nk2 = n1p >> 5;                // at most 8 k-steps
+    bf16x8 ha[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ha[u] = u < nk2 ? *reinterpret_cast<const bf16x8*>(&Hs[fr * HS + u * 32 + fq * 8]) : zero8();
+    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
+    for (int f0 = wave; f0 < nf2; f0 += 8) {
+        // two column fragments at a time: their loads are in flight together
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        bf16x8 fb[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = (f0 + 4 * q) * 16 + fr;
+            const bf16* __restrict__ wrow = (const bf16*)p.W2 + (long)(n < p.N2 ? n : 0) * p.ldw2;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = u * 32 + fq * 8;
+                fb[q][u] = (u < nk2 && k < p.N1 && n < p.N2 && f0 + 4 * q < nf2) ? *reinterpret_cast<const bf16x8*>(wrow + k) : zero8();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[q][u], ha[u], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = f0 + 4 * q;
+            const int nb = f * 16 + fq * 4;
+            if (f >= nf2 || !row_ok || nb >= p.N2) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[q][r];
+                if (p.bias2 && nb + r < p.N2) v[r] += p.bias2[nb + r];
+                v[r] = small_act(v[r], p.act2) * out_scale;
+            }
+            if (p.c_f32) {
+                float* c = (float*)p.C + m * p.ldc + nb;
+                if (nb + 3 < p.N2 && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (nb + r < p.N2) c[r] = v[r];
+                }
+            } else {
+                bf16* c = (bf16*)p.C + m * p.ldc + nb;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                if (nb + 3 < p.N2 && (p.ldc & 3) == 0) *reinterpret_cast<bf16x4*>(c) = o;
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (nb + r < p.N2) c[r] = o[r];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 __device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
@@ -945,6 +1068,19 @@ extern "C" int stes_gemm(const stes_gemm_args* a, void* stream) {
     const StesDet det = a->col_sum ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u};
     if (wide) hipLaunchKernelGGL(gemm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv, det);
     else hipLaunchKernelGGL(gemm_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, m_tiles, n_tiles, m_slots, dv, det);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_gemm_small2(const stes_gemm2_args* a, void* stream) {
+    STES_CHECK(a && a->A && a->W1 && a->W2 && a->C, STES_ERR_ARG, "stes_gemm_small2: null pointer");
+    STES_CHECK(a->M > 0 && a->K1 > 0 && a->N1 > 0 && a->N2 > 0, STES_ERR_ARG, "stes_gemm_small2: empty shape");
+    STES_CHECK(a->K1 % 8 == 0 && a->N1 % 8 == 0 && a->lda % 8 == 0 && a->ldw1 % 8 == 0 && a->ldw2 % 8 == 0, STES_ERR_ARG,
+               "stes_gemm_small2: K1, N1 and the leading dimensions must be multiples of 8");
+    STES_CHECK(a->N1 <= 256 && a->K1 <= 1024 && a->N2 <= 1024, STES_ERR_UNSUPPORTED, "stes_gemm_small2: N1 <= 256, K1 <= 1024, N2 <= 1024");
+    STES_CHECK(a->act1 >= 0 && a->act1 <= 2 && a->act2 >= 0 && a->act2 <= 2, STES_ERR_ARG, "stes_gemm_small2: act is 0, 1 or 2");
+    STES_CHECK(a->M <= (1L << 31), STES_ERR_UNSUPPORTED, "stes_gemm_small2: too many rows");
+    hipLaunchKernelGGL(gemm_small2_kernel, dim3((unsigned)((a->M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *a);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -209,8 +209,9 @@ class Block:
             # squeeze-excite: mean over H,W -> fc1 + ReLU -> fc2 -> sigmoid, the two FCs as MFMA GEMMs over the frames
             lib.call("stes_chan_pool", p(self.c2), p(self.bn2.scale), p(self.bn2.shift), None, None, p(self.pooled), self.N, HWo, cmid, 1.0 / HWo)
         se = self.se
-        lib.gemm(self.pooled, self.se1.w_bf, self.hidden, self.N, self.rd, cmid, bias=se.fc1.bias, act=1)
-        lib.gemm(self.hidden, self.se2.w_bf, self.segate, self.N, cmid, self.rd, bias=se.fc2.bias, act=2)
+        # (fc1 + ReLU and fc2 + sigmoid in one launch: two launches of a few microseconds sat in the chain between two large kernels)
+        lib.gemm2(self.pooled, self.se1.w_bf, self.hidden, self.se2.w_bf, self.segate, self.N, cmid, self.rd, cmid,
+                  bias1=se.fc1.bias, act1=1, bias2=se.fc2.bias, act2=2, ldw1=self.se1.Kp, ldw2=self.se2.Kp)
         def shortcut():
             if self.down:
                 rowmap = (self.stride, self.Ho, self.Wo, self.Hi, self.Wi) if self.stride > 1 else None
@@ -284,8 +285,8 @@ class Block:
         se, rd = self.se, self.rd
         lib.call("stes_se_bwd_pool", p(self.c2), p(bn2.scale), p(bn2.shift), p(dA3), p(S4), p(dgate), p(self.segate), p(dpre2),
                  self.N, HWo, cmid)
-        lib.gemm(dpre2, self.se2.wT_bf, dpre1, self.N, rd, cmid, ldw=self.se2.Np, relu_mask=self.hidden, ldmask=rd)
-        lib.gemm(dpre1, self.se1.wT_bf, dpool, self.N, cmid, rd, ldw=self.se1.Np, out_scale=1.0 / HWo)
+        lib.gemm2(dpre2, self.se2.wT_bf, dpre1, self.se1.wT_bf, dpool, self.N, cmid, rd, cmid, relu_mask1=self.hidden, ldmask1=rd,
+                  out_scale=1.0 / HWo, ldw1=self.se2.Np, ldw2=self.se1.Np)
         def se_wgrads():
             lib.wgrad(dpre2, self.hidden, g(se.fc2.weight), self.N, cmid, rd, dbias=g(se.fc2.bias))
             lib.wgrad(dpre1, self.pooled, g(se.fc1.weight), self.N, rd, cmid, dbias=g(se.fc1.bias))

@@ -44,6 +44,14 @@ GemmArgs = _struct("GemmArgs", [
     ("e_scale", _P), ("e_shift", _P), ("e_res", _P), ("e_ldres", _I64), ("e_rscale", _P), ("e_rshift", _P),
     ("e_slice", _P), ("e_slice_n", _I32)])
 
+Gemm2Args = _struct("Gemm2Args", [
+    ("A", _P), ("lda", _I64), ("M", _I64), ("K1", _I32),
+    ("W1", _P), ("ldw1", _I32), ("N1", _I32), ("bias1", _P), ("act1", _I32),
+    ("relu_mask1", _P), ("ldmask1", _I64),
+    ("H", _P), ("ldh", _I64),
+    ("W2", _P), ("ldw2", _I32), ("N2", _I32), ("bias2", _P), ("act2", _I32), ("out_scale", _F32),
+    ("C", _P), ("ldc", _I64), ("c_f32", _I32)])
+
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
     ("q_scale", _P), ("q_shift", _P), ("q_relu", _I32), ("q_gate", _P), ("gate_group", _I32),
@@ -77,6 +85,7 @@ GruArgs = _struct("GruArgs", [
 _SIGS = {
     "stes_gemm": [_P, _P],
     "stes_wgrad": [_P, _P],
+    "stes_gemm_small2": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
@@ -398,6 +407,24 @@ def gemm(A, W, Cout, M, N, K, *, lda=None, ldw=None, ldc=None, A0=None, lda0=0, 
         _timed(_gemm_kernel(a), byt, fl, lambda: check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm"))
         return
     check(lib().stes_gemm(C.byref(a), stream()), "stes_gemm")
+
+
+def gemm2(A, W1, H, W2, Cout, M, K1, N1, N2, *, bias1=None, act1=0, relu_mask1=None, ldmask1=0, bias2=None, act2=0, out_scale=0.0,
+          ldw1=None, ldw2=None):
+    """H = act1(A W1^T + bias1) [masked], Cout = act2(H W2^T + bias2) * out_scale in one launch; see stes_gemm_small2 in
+    include/stes.h (the squeeze-excite FC pair and its input-gradient pair)."""
+    a = Gemm2Args()
+    a.A, a.lda, a.M, a.K1 = ptr(A), K1, M, K1
+    a.W1, a.ldw1, a.N1, a.bias1, a.act1 = ptr(W1), ldw1 if ldw1 is not None else K1, N1, ptr(bias1), act1
+    a.relu_mask1, a.ldmask1 = ptr(relu_mask1), ldmask1
+    a.H, a.ldh = ptr(H), N1
+    a.W2, a.ldw2, a.N2, a.bias2, a.act2, a.out_scale = ptr(W2), ldw2 if ldw2 is not None else N1, N2, ptr(bias2), act2, out_scale
+    a.C, a.ldc, a.c_f32 = ptr(Cout), N2, int(Cout.dtype == torch.float32)
+    fn = lambda: check(lib().stes_gemm_small2(C.byref(a), stream()), "stes_gemm_small2")
+    if TIMING is not None:
+        _timed("gemm_small2_kernel", 2 * M * (K1 + N1) + 2 * N1 * (K1 + N2) + M * N2 * (4 if a.c_f32 else 2), 2 * M * N1 * (K1 + N2), fn)
+        return
+    fn()
 
 
 def wgrad(P, Q, dW, M, N1, N2, *, ldp=None, ldq=None, lddw=None, Q0=None, ldq0=0, k0=0,

@@ -410,3 +410,37 @@ def test_gemm_stem_tail_epilogue_equals_gemm_then_bn_act():
     lib.gemm(X, W, out, M, N, K, tail=(es, eb, None, None, None, slc, fold))
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)) and torch.equal(slc.view(torch.int16), slc_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,K1,N1,N2,f32", [(1024, 320, 80, 320, True), (1024, 64, 8, 64, True), (50, 768, 192, 768, False), (17, 128, 32, 128, True),
+                                           (1024, 768, 192, 768, True), (3, 8, 8, 8, False), (100, 1024, 256, 1024, True)])
+def test_gemm_small2_equals_two_small_products(M, K1, N1, N2, f32):
+    """The squeeze-excite FC pair in one launch (H = relu(A W1^T + b1), C = sigmoid(H W2^T + b2)) and its backward pair (masked
+    H, scaled fp32 C) against two stes_gemm calls: same roundings (H bf16 in between), fp32 summation order aside."""
+    from spot_amd import lib
+    BF = torch.bfloat16
+
+    def close(a, b, rtol, atol):
+        assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
+    g = torch.Generator().manual_seed(M + K1 + N1 + N2)
+    A = (torch.randn(M, K1, generator=g)).to(BF).cuda()
+    W1 = (torch.randn(N1, K1, generator=g) / K1 ** 0.5).to(BF).cuda(); W2 = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).to(BF).cuda()
+    b1 = torch.randn(N1, generator=g).cuda() * 0.1; b2 = torch.randn(N2, generator=g).cuda() * 0.1
+    mask = torch.randn(M, N1, generator=g).to(BF).cuda()
+    for fwd in (True, False):
+        H1 = torch.full((M, N1), 7.0, dtype=BF, device="cuda"); H2 = torch.full_like(H1, 9.0)
+        dt = torch.float32 if f32 else BF
+        C1 = torch.full((M, N2), 7.0, dtype=dt, device="cuda"); C2 = torch.full_like(C1, 9.0)
+        if fwd:
+            lib.gemm(A, W1, H1, M, N1, K1, bias=b1, act=1)
+            lib.gemm(H1, W2, C1, M, N2, N1, bias=b2, act=2)
+            lib.gemm2(A, W1, H2, W2, C2, M, K1, N1, N2, bias1=b1, act1=1, bias2=b2, act2=2)
+        else:
+            lib.gemm(A, W1, H1, M, N1, K1, relu_mask=mask, ldmask=N1)
+            lib.gemm(H1, W2, C1, M, N2, N1, out_scale=0.25)
+            lib.gemm2(A, W1, H2, W2, C2, M, K1, N1, N2, relu_mask1=mask, ldmask1=N1, out_scale=0.25)
+        torch.cuda.synchronize()
+        close(H2.float(), H1.float(), 1e-2, 1e-2)
+        close(C2.float(), C1.float(), 2e-2, 1e-2)
+        if not fwd:
+            assert bool(((H2.float() == 0) | (mask.float() > 0)).all())
