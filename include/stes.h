@@ -166,6 +166,12 @@ int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shi
 
 /* out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1), act = relu(scale*c+shift)
  * when scale is given.  Squeeze of timm SEModule, its backward, and the head's global pool.   */
+/* out = bf16(relu(scale * c + shift) * gate[row / HW]): the squeeze-excited activation in front of a bottleneck's last 1x1
+ * convolution (timm Bottleneck: conv2's bn + act, then SEModule's x * gate) written out, for the layers where stes_gemm's
+ * operand prologue is slower than this pass plus a plain product (the 768-channel blocks); same arithmetic and rounding as
+ * that prologue.  c, out: [N*HW][C] bf16; gate: [N][C] fp32. */
+int stes_bn_act_gate(const uint16_t* c, const float* scale, const float* shift, const float* gate, uint16_t* out, int N, int HW,
+                     int C, void* stream);
 int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, const uint16_t* mul, float* out,
                    uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream);
 

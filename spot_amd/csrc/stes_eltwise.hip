@@ -609,6 +609,41 @@ extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const
     return STES_OK;
 }
 
+// out[m][c] = bf16(relu(c[m][c] * scale[c] + shift[c]) * gate[m / HW][c]): the operand of a bottleneck's last 1x1 convolution
+// written out once.  Where that convolution runs on the tiled GEMM (768 channels) its operand prologue costs more than this
+// pass plus a plain product, and the weight gradient reads the same tensor instead of transforming its operand again.
+__global__ __launch_bounds__(TPB) void bn_act_gate_kernel(const bf16* __restrict__ c, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ gate,
+                                                          bf16* __restrict__ out, long M, int C, FastDiv fd_hw) {
+    const int CH = C / 8;
+    const long gt = (long)blockIdx.x * TPB + threadIdx.x, TT = (long)gridDim.x * TPB;
+    const int chunk = (int)(gt % CH), c0 = chunk * 8;
+    float s[8], b[8];
+    load8f(scale + c0, s); load8f(shift + c0, b);
+    for (long m = gt / CH; m < M; m += TT / CH) {
+        float v[8], g[8];
+        load8b(c + m * C + c0, v);
+        load8f(gate + (long)fdiv((uint32_t)m, fd_hw) * C + c0, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * s[i] + b[i], 0.f) * g[i];
+        store8b(out + m * C + c0, v);
+    }
+}
+
+extern "C" int stes_bn_act_gate(const uint16_t* c, const float* scale, const float* shift, const float* gate, uint16_t* out, int N, int HW,
+                                int C, void* stream) {
+    STES_CHECK(c && scale && shift && gate && out && N > 0 && HW > 0, STES_ERR_ARG, "stes_bn_act_gate: null pointer");
+    STES_CHECK(C % 8 == 0, STES_ERR_ARG, "stes_bn_act_gate: C must be a multiple of 8");
+    const long M = (long)N * HW;
+    STES_CHECK(M < (1L << 32), STES_ERR_UNSUPPORTED, "stes_bn_act_gate: too many rows");
+    static const int cap = resident_blocks(bn_act_gate_kernel);
+    const int grid = flat_grid(M, C / 8, cap < 1024 ? cap : 1024);
+    hipLaunchKernelGGL(bn_act_gate_kernel, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)c, scale, shift, gate, (bf16*)out, M, C,
+                       make_fastdiv(HW));
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
 extern "C" int stes_chan_pool(const uint16_t* c, const float* scale, const float* shift, const uint16_t* mul, float* out,
                               uint16_t* out_bf16, int N, int HW, int C, float norm, void* stream) {
     STES_CHECK(c && (out || out_bf16) && N > 0 && HW > 0, STES_ERR_ARG, "stes_chan_pool: null pointer");

@@ -89,6 +89,7 @@ _SIGS = {
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
+    "stes_bn_act_gate": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
     "stes_clip_gate_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
     "stes_clip_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -274,6 +275,7 @@ _KERNEL_OF = {
     "stes_gsm_bwd_dx": (lambda a: "gsm_bwd_dx_kernel<%d>" % (4 if _geom_of(a)[1] == 8 else 8), _gsm_bytes(4, 1)),
     "stes_bn_act_residual": ("bn_act_residual_kernel", _bn_act_bytes),
     # (c, scale, shift, mul, out, out_bf16, N, HW, C, norm): the map once (twice with a multiplier)
+    "stes_bn_act_gate": ("bn_act_gate_kernel", lambda a: 4 * a[5] * a[6] * a[7]),
     "stes_chan_pool": ("chan_pool_kernel", lambda a: 2 * a[6] * a[7] * a[8] * (1 + (a[3] is not None))),
     # (c2, scale, shift, dA3, S, dgate, gate, dpre, N, HW, C): the raw map and the gradient once each
     "stes_se_bwd_pool": ("se_bwd_pool_kernel", lambda a: 4 * a[8] * a[9] * a[10]),

@@ -241,6 +241,27 @@ def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
         lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
 
 
+def test_bn_act_gate_is_the_gemm_prologue_written_out():
+    """stes_bn_act_gate = relu(scale * c + shift) * gate per image, rounded once; the plain product of it equals the product with
+    the operand prologue bit for bit (same arithmetic in both places)."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(9)
+    N, HW, Cc, No = 64, 49, 768, 128            # (large enough for both products to run on the tiled kernel)
+    c = bfr(N * HW, Cc, g=g); gate = dev(torch.rand(N, Cc, generator=g))
+    sc, sh = dev(torch.rand(Cc, generator=g) + 0.5), dev(torch.randn(Cc, generator=g) * 0.3)
+    out = torch.full((N * HW, Cc), 7.0, dtype=BF, device="cuda")
+    lib.call("stes_bn_act_gate", lib.ptr(dev(c)), lib.ptr(sc), lib.ptr(sh), lib.ptr(gate), lib.ptr(out), N, HW, Cc)
+    torch.cuda.synchronize()
+    want = (torch.relu(c.float().cuda() * sc + sh) * gate.repeat_interleave(HW, 0)).to(BF)
+    close(out.float().cpu(), want.float().cpu(), 1e-2, 1e-3)          # (the kernel contracts scale * c + shift into one fma: one bf16 ulp)
+    W = dev((torch.randn(No, Cc, generator=g) / Cc ** 0.5).to(BF))
+    a = torch.empty(N * HW, No, dtype=BF, device="cuda"); b = torch.empty_like(a)
+    lib.gemm(out, W, a, N * HW, No, Cc)
+    lib.gemm(dev(c), W, b, N * HW, No, Cc, scale=sc, shift=sh, relu=True, gate=gate, gate_group=HW)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
 def test_bn_finalize_and_act_residual():
     from spot_amd import lib
     g = torch.Generator().manual_seed(5)
