@@ -96,6 +96,27 @@ typedef struct {
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
+/* Evaluation forward of one stage-3 bottleneck of RegNet-Y 800MF (14 x 14 x 320, stride 1, identity shortcut, squeeze-excite
+ * with 80 hidden units, gated shift on the first 80 input channels) in ONE kernel, an image's activations staying in LDS
+ * between the three convolutions: timm Bottleneck conv1 -> bn/act -> grouped conv2 -> bn/act -> SE -> conv3 -> bn -> + shortcut
+ * -> act as the reference builds it (train_e2e_spatial.py:305-314), with model/shift.py:157-161's substitution of the gated
+ * shift's result G for the first `fold` channels of conv1's input.  BatchNorms are the evaluation-mode affine maps
+ * (scale, shift as stes_bn_finalize gives them with training == 0).  Same roundings as the kernel sequence
+ * stes_gemm / stes_conv3x3g_fwd_pool / stes_gemm_small2 / stes_gemm with the block-tail epilogue.
+ * X: block input [N*H*W][C]; G: [N*H*W][fold]; W1, W3: [C][C] bf16 (W1 with the fold-permuted columns stes_gemm takes);
+ * wp2: stes_pack_conv3x3g's forward pack; Wse1 [rd][C], Wse2 [C][rd] bf16 with fp32 biases; out: [N*H*W][C];
+ * slice (optional): the first slice_n channels of out as [N*H*W][slice_n] (the next block's gated-shift slice). */
+typedef struct {
+    const uint16_t* X; const uint16_t* G;
+    const uint16_t* W1; const float* s1; const float* b1;
+    const uint16_t* wp2; const float* s2; const float* b2;
+    const uint16_t* Wse1; const float* bse1; const uint16_t* Wse2; const float* bse2;
+    const uint16_t* W3; const float* s3; const float* b3;
+    uint16_t* out; uint16_t* slice; int32_t slice_n;
+    int32_t N, H, W, C, rd, fold;
+} stes_block_eval_args;
+int stes_block_eval_s3(const stes_block_eval_args* a, void* stream);
+
 /* Two chained small products in one launch, for the squeeze-excite block's pair of 1x1 convolutions on the pooled vectors
  * (timm SEModule fc1 -> ReLU -> fc2 -> sigmoid as the reference builds it, train_e2e_spatial.py:305-314) and their
  * input-gradient pair in backward:

@@ -189,6 +189,19 @@ class Block:
             lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
             a_src = self.Xs
         self.a_src = a_src
+        if (not train and e.block_fused and self.kind == "gsm" and cin == cmid == cout
+                and lib.block_eval_takes(cmid, self.Hi, self.Wi, self.rd, self.fold, self.stride, self.down)):
+            # evaluation, stage-3 identity blocks: every BatchNorm is a fixed affine map and one 14x14 image's activations fit
+            # a compute unit's LDS, so the three convolutions and the squeeze-excite run per image in one kernel and only the
+            # block input and output touch memory (c1, c2 and the pooled/hidden/gate vectors never exist)
+            for bn in (self.bn1, self.bn2, self.bn3):
+                bn.finalize(Mo, train)
+            slc = (nxt.Xc, nxt.fold) if nxt is not None and nxt.kind == "gsm" else (None, 0)
+            se = self.se
+            lib.block_eval(X, self.G, self.l1.w_bf, (self.bn1.scale, self.bn1.shift), self.wp2_f, (self.bn2.scale, self.bn2.shift),
+                           self.se1.w_bf, se.fc1.bias, self.se2.w_bf, se.fc2.bias, self.l3.w_bf, (self.bn3.scale, self.bn3.shift),
+                           self.out, slc[0], slc[1], self.N)
+            return self.out
         lib.gemm(a_src, self.l1.w_bf, self.c1, Mi, cmid, cin, A0=a0, lda0=k0, k0=k0, stats=st(self.bn1))
         self.bn1.finalize(Mi, train)
         s2 = st(self.bn2)
@@ -426,6 +439,7 @@ class Engine:
         self._cast_table = None
         self.bns = []                                  # every BatchNorm site (BN.__init__ registers itself)
         self._eval_bn_key, self._eval_bn_live = None, False
+        self.block_fused = os.environ.get("STES_BLOCK_FUSED", "1") != "0"    # evaluation: stage-3 identity blocks as one kernel each
         self._grad_views = None
         self._grad_of = {}
         self._flatten()

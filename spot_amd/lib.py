@@ -52,6 +52,15 @@ Gemm2Args = _struct("Gemm2Args", [
     ("W2", _P), ("ldw2", _I32), ("N2", _I32), ("bias2", _P), ("act2", _I32), ("out_scale", _F32),
     ("C", _P), ("ldc", _I64), ("c_f32", _I32)])
 
+BlockEvalArgs = _struct("BlockEvalArgs", [
+    ("X", _P), ("G", _P),
+    ("W1", _P), ("s1", _P), ("b1", _P),
+    ("wp2", _P), ("s2", _P), ("b2", _P),
+    ("Wse1", _P), ("bse1", _P), ("Wse2", _P), ("bse2", _P),
+    ("W3", _P), ("s3", _P), ("b3", _P),
+    ("out", _P), ("slice", _P), ("slice_n", _I32),
+    ("N", _I32), ("H", _I32), ("W", _I32), ("C", _I32), ("rd", _I32), ("fold", _I32)])
+
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
     ("q_scale", _P), ("q_shift", _P), ("q_relu", _I32), ("q_gate", _P), ("gate_group", _I32),
@@ -86,6 +95,7 @@ _SIGS = {
     "stes_gemm": [_P, _P],
     "stes_wgrad": [_P, _P],
     "stes_gemm_small2": [_P, _P],
+    "stes_block_eval_s3": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
@@ -425,6 +435,30 @@ def gemm2(A, W1, H, W2, Cout, M, K1, N1, N2, *, bias1=None, act1=0, relu_mask1=N
     fn = lambda: check(lib().stes_gemm_small2(C.byref(a), stream()), "stes_gemm_small2")
     if TIMING is not None:
         _timed("gemm_small2_kernel", 2 * M * (K1 + N1) + 2 * N1 * (K1 + N2) + M * N2 * (4 if a.c_f32 else 2), 2 * M * N1 * (K1 + N2), fn)
+        return
+    fn()
+
+
+def block_eval_takes(C_, H, W, rd, fold, stride, down):
+    """Shapes for which stes_block_eval_s3 runs a whole bottleneck's evaluation forward in one kernel (the rule in
+    stes_block_eval.hip: RegNet-Y 800MF's stage-3 identity blocks)."""
+    return (C_, H, W, rd, fold, stride) == (320, 14, 14, 80, 80, 1) and not down
+
+
+def block_eval(X, G, W1, bn1, wp2, bn2, Wse1, bse1, Wse2, bse2, W3, bn3, out, slc, slice_n, N):
+    """One stage-3 bottleneck in evaluation mode; bn* = (scale, shift) of the evaluation-mode BatchNorms; see stes_block_eval_s3."""
+    a = BlockEvalArgs()
+    a.X, a.G = ptr(X), ptr(G)
+    a.W1, a.s1, a.b1 = ptr(W1), ptr(bn1[0]), ptr(bn1[1])
+    a.wp2, a.s2, a.b2 = ptr(wp2), ptr(bn2[0]), ptr(bn2[1])
+    a.Wse1, a.bse1, a.Wse2, a.bse2 = ptr(Wse1), ptr(bse1), ptr(Wse2), ptr(bse2)
+    a.W3, a.s3, a.b3 = ptr(W3), ptr(bn3[0]), ptr(bn3[1])
+    a.out, a.slice, a.slice_n = ptr(out), ptr(slc), slice_n
+    a.N, a.H, a.W, a.C, a.rd, a.fold = N, 14, 14, 320, 80, 80
+    fn = lambda: check(lib().stes_block_eval_s3(C.byref(a), stream()), "stes_block_eval_s3")
+    if TIMING is not None:
+        m = N * 196
+        _timed("block_eval_s3_kernel", 2 * m * (320 + 80 + 320 + 320 + slice_n), 2 * m * (2 * 320 * 320 + 320 * 144), fn)
         return
     fn()
 

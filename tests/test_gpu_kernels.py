@@ -241,6 +241,45 @@ def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
         lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
 
 
+@pytest.mark.parametrize("N,with_slice", [(43, True), (300, False)])
+def test_block_eval_s3_equals_the_kernel_sequence(N, with_slice):
+    """A stage-3 bottleneck's evaluation forward in one kernel against the sequence it replaces (stes_gemm with the gated-shift
+    split, stes_conv3x3g_fwd_pool, stes_gemm_small2, stes_gemm with the block-tail epilogue): same roundings, so the results
+    agree to one bf16 ulp here and there (fp32 summation order inside the products)."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(31 + N)
+    Cc, HW, rd, fold = 320, 196, 80, 80
+    M = N * HW
+    X = dev(bfr(M, Cc, g=g).abs()); G = dev(bfr(M, fold, g=g).abs())
+    W1 = dev((torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(BF)); W3 = dev((torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(BF))
+    w2 = dev(torch.randn(Cc, 16, 3, 3, generator=g) / 12.0)
+    wpf = torch.empty(Cc // 16 * 5 * 512, dtype=BF, device="cuda"); wpd = torch.empty_like(wpf)
+    lib.call("stes_pack_conv3x3g", lib.ptr(w2), lib.ptr(wpf), lib.ptr(wpd), Cc // 16, 1)
+    Wse1 = dev((torch.randn(rd, Cc, generator=g) / Cc ** 0.5).to(BF)); Wse2 = dev((torch.randn(Cc, rd, generator=g) / rd ** 0.5).to(BF))
+    bse1 = dev(torch.randn(rd, generator=g) * 0.1); bse2 = dev(torch.randn(Cc, generator=g) * 0.1)
+    bns = [(dev(torch.rand(Cc, generator=g) + 0.5), dev(torch.randn(Cc, generator=g) * 0.2)) for _ in range(3)]
+    # ---- the kernel sequence
+    c1 = torch.empty(M, Cc, dtype=BF, device="cuda"); c2 = torch.empty_like(c1); ref = torch.empty_like(c1)
+    pooled = torch.empty(N, Cc, dtype=BF, device="cuda"); hidden = torch.empty(N, rd, dtype=BF, device="cuda"); gate = torch.empty(N, Cc, device="cuda")
+    ref_slice = torch.full((M, 80), 7.0, dtype=BF, device="cuda")
+    lib.gemm(X, W1, c1, M, Cc, Cc, A0=G, lda0=fold, k0=fold)
+    lib.call("stes_conv3x3g_fwd_pool", lib.ptr(c1), lib.ptr(wpf), lib.ptr(c2), lib.ptr(bns[0][0]), lib.ptr(bns[0][1]), lib.ptr(bns[1][0]),
+             lib.ptr(bns[1][1]), lib.ptr(pooled), N, 14, 14, 14, 14, 1, Cc)
+    lib.gemm2(pooled, Wse1, hidden, Wse2, gate, N, Cc, rd, Cc, bias1=bse1, act1=1, bias2=bse2, act2=2)
+    lib.gemm(c2, W3, ref, M, Cc, Cc, scale=bns[1][0], shift=bns[1][1], relu=True, gate=gate, gate_group=HW,
+             tail=(bns[2][0], bns[2][1], X, None, None, ref_slice if with_slice else None, 80 if with_slice else 0))
+    # ---- one kernel
+    out = torch.full((M, Cc), 9.0, dtype=BF, device="cuda"); slc = torch.full((M, 80), 9.0, dtype=BF, device="cuda")
+    lib.block_eval(X, G, W1, bns[0], wpf, bns[1], Wse1, bse1, Wse2, bse2, W3, bns[2], out, slc if with_slice else None, 80 if with_slice else 0, N)
+    torch.cuda.synchronize()
+    a, b = out.float().cpu(), ref.float().cpu()
+    assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())
+    close(a, b, 2e-2, 2e-2)
+    if with_slice:
+        assert torch.equal(slc.view(torch.int16), out[:, :80].contiguous().view(torch.int16))
+        assert float((slc.float() - ref_slice.float()).norm() / ref_slice.float().norm()) < 2e-3
+
+
 def test_bn_act_gate_is_the_gemm_prologue_written_out():
     """stes_bn_act_gate = relu(scale * c + shift) * gate per image, rounded once; the plain product of it equals the product with
     the operand prologue bit for bit (same arithmetic in both places)."""
