@@ -22,6 +22,6 @@ for cfg in train_tsm_mingru infer_fwd infer_long_video; do
 done
 timeout -k 10 120 python3 tools/bench_augment.py > $out/augment.txt 2>&1
 # the evaluation forward (configuration infer_fwd) by kernel
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_infer -o ${tag}i -- python3 bench.py --config infer_fwd --steps 5 --warmup 2 --no-cpu-baseline > $out/prof_infer.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_infer -o ${tag}i -- python3 bench.py --config infer_fwd --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/prof_infer.log 2>&1
 rm -f $out/prof_infer/*_kernel_trace.csv
 echo profiles done

@@ -58,8 +58,8 @@ if os.path.exists(f"{src}/prof_infer/{tag}i_kernel_stats.csv"):
     with open(f"profiles/{tag}_infer_fwd_kernel_stats.md", "w") as fp:
         subprocess.run([sys.executable, "tools/prof_summary.py", f"{src}/prof_infer/{tag}i_kernel_stats.csv", "--steps", "7", "--title",
                         "Evaluation forward (predict) of 16 clips x 64 frames x 224p, 1 MI355X", "--note",
-                        "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config infer_fwd --steps 5 --warmup 2 "
-                        f"--no-cpu-baseline` (7 forward passes traced; model construction contributes the copy / fill kernels at the bottom). "
+                        "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config infer_fwd --steps 5 --warmup 2 --no-cpu-baseline "
+                        f"--no-roofline` (7 forward passes traced; model construction contributes the copy / fill kernels at the bottom). "
                         f"bench.py un-profiled: {di['ms_per_step']:.2f} ms per pass = {di['value']:.0f} frames/s (`profiles/{tag}_bench_infer_fwd.json`)."],
                        stdout=fp, check=True)
 print(d["ms_per_step"], d["value"], r["kernel"], r["frac"], r["traffic"], r["avg_launch_us"])
