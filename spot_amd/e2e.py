@@ -247,6 +247,20 @@ class E2EModel(BaseRGBModel):
                 return pred_cls, pred_cls_score, pred_loc
             return pred_cls, pred_cls_score
 
+    def predict_async(self, seq):
+        """predict() without the host round trip: (class scores [B,T,classes], locations [B,T,2] | None) as device tensors of
+        their own (the next forward does not overwrite them), nothing waited for.  A caller that walks a long video enqueues
+        the next batch before it reads the previous one back, so the GPU is never idle while the host issues launches
+        (reference inference_on_mp4.py:204-243 reads every batch back before it starts the next)."""
+        if seq.device != torch.device(self.device) and str(seq.device) != str(self.device):
+            seq = seq.to(self.device, non_blocking=True)
+        self._model.eval()
+        with torch.no_grad():
+            pred_dict = self._model(seq)
+            scores = torch.softmax(pred_dict["im_feat"], axis=2)
+            loc = pred_dict["loc_feat"].reshape(seq.shape[0], -1, 2).sigmoid() if self._model._predict_location else None
+        return scores, loc
+
     # ------------------------------------------------------------------ fused training step (HIP loss + backward + AdamW)
     def train_step(self, frame, label, xy, lr, fg_weight=5.0, grad_scale=1.0, ext_denoms=None, optimizer_step=True,
                    after_backward=None, grad_mul=1.0, on_ready=None):

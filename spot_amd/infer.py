@@ -56,6 +56,16 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
     n_frames = frames.shape[0]
     acc = ScoreAccumulator(n_frames, len(classes) + 1)
     full_batch_seen = False
+    pipelined = hasattr(model, "predict_async")
+    pending = None
+
+    def take(starts, scores, loc):
+        if torch.is_tensor(scores):
+            scores = scores.cpu().numpy()
+            loc = None if loc is None else loc.cpu().numpy()
+        for i, s in enumerate(starts):
+            acc.add(s, scores[i], None if loc is None else loc[i])
+
     for starts in window_batches(n_frames, clip_len, batch_size, rank, world):
         clips = []
         for s in starts:
@@ -71,10 +81,18 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
             clips += [clips[-1]] * (batch_size - len(clips))
         full_batch_seen = full_batch_seen or len(clips) == batch_size
         batch = torch.stack(clips, 0)
-        out = model.predict(batch)
-        scores, loc = out[1], (out[2] if len(out) > 2 else None)
-        for i, s in enumerate(starts):
-            acc.add(s, scores[i], None if loc is None else loc[i])
+        if pipelined:
+            # this batch is enqueued before the previous one's results are read back: the host's launches for it overlap the
+            # GPU's work on the previous batch instead of following the read-back's wait
+            cur = model.predict_async(batch)
+            if pending is not None:
+                take(*pending)
+            pending = (starts, cur[0], cur[1])
+        else:
+            out = model.predict(batch)
+            take(starts, out[1], out[2] if len(out) > 2 else None)
+    if pending is not None:
+        take(*pending)
     if gather is not None:                      # multi-rank: disjoint frame ranges, sum on the host
         acc.scores, acc.support, acc.locations = gather(acc.scores, acc.support, acc.locations)
     scores, locations = acc.finish()
