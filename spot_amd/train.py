@@ -2,14 +2,16 @@
 the parts that touch the model -- optimizer, warm-up + cosine schedule, epochs, checkpoints, resume -- with the reference's
 flag names, file names and file contents, so a `save_dir` written here is read by the reference and the other way round.
 
-What is NOT here is the reference's JPEG frame reader (dataset/frame.py:20-65): at >10^4 frames/s a GPU is fed from
-pre-decoded clips; its random augmentation (dataset/frame.py:78-140) runs on the GPU under `--augment` (spot_amd/augment.py).  `frame_dir` holds shards `train_*.npz` / `val_*.npz` with
+At >10^4 frames/s a GPU is best fed from pre-decoded clips; the loader's random augmentation (dataset/frame.py:78-140) runs on
+the GPU under `--augment` (spot_amd/augment.py).  `frame_dir` holds shards `train_*.npz` / `val_*.npz` with
 
     frame uint8 [n, clip_len, 3, H, W]   decoded RGB frames (the stem normalises them on the GPU)
     label int64 [n, clip_len]            0 = background
     xy    float32 [n, clip_len, 2]       event location in [0, 1]
 
-or is the literal string `synthetic[:n_clips]`.  `--criterion map` (best epoch by validation mAP, from `--start_val_epoch`
+or is the literal string `synthetic[:n_clips]`, or -- the reference's own layout -- holds JPEG frames `<video>/000123.jpg` with the
+label files `data/<dataset>/{train,val}.json` (spot_amd/dataset.py: the reference's frame reader and clip sampler; frames of
+another size than crop_dim need `--augment`).  `--criterion map` (best epoch by validation mAP, from `--start_val_epoch`
 on) additionally needs whole validation videos: `val.json` in the reference's label format (data/<dataset>/val.json) and
 `val_videos/<video>.npy`, uint8 [num_frames, 3, H, W], which are memory-mapped; `synthetic` makes two random videos.
 
@@ -68,6 +70,10 @@ def get_args(argv=None):
     p.add_argument("--fused", action="store_true", help="HIP loss + backward + AdamW (implied under torchrun)")
     p.add_argument("--mixup", action="store_true", help="the reference loader's mixup (dataset/frame.py:338-353; train_e2e_spatial.py:141); "
                    "soft labels: not with --fused or --predict_location")
+    p.add_argument("--dilate_len", type=int, default=0, help="label dilation when training (JPEG frame directories)")
+    p.add_argument("--fg_upsample", type=float, default=None, help="sample around events with probability 1 - fg_upsample (JPEG frame directories)")
+    p.add_argument("-j", "--num_workers", type=int, default=None, help="base number of decoding workers (JPEG frame directories)")
+    p.add_argument("--debug_only", action="store_true", help="500 frames per epoch instead of 500,000 (train_e2e_spatial.py:1035-1037)")
     p.add_argument("--augment", action="store_true",
                    help="the reference loader's random augmentation (dataset/frame.py:78-140) on the GPU; shards may then hold "
                         "frames of any size (validation clips are resized to crop_dim)")
@@ -200,8 +206,35 @@ def _get_loaders(args, num_classes, rank=0, world=1):
         return mk(2 * rank, n), mk(2 * rank + 1, max(bs, n // 4))
     tr, va = (glob.glob(os.path.join(args.frame_dir, f"{s}_*.npz")) for s in ("train", "val"))
     if not tr or not va:
-        raise FileNotFoundError(f"no train_*.npz / val_*.npz shards in {args.frame_dir}")
+        if os.path.exists(os.path.join("data", args.dataset, "train.json")):
+            return _jpeg_loaders(args, bs, rank, world)
+        raise FileNotFoundError(f"no train_*.npz / val_*.npz shards in {args.frame_dir} and no data/{args.dataset}/train.json "
+                                "for a JPEG frame directory")
     return ClipShards(tr, bs, rank, world), ClipShards(va, bs, rank, world)
+
+
+EPOCH_NUM_FRAMES, BASE_NUM_WORKERS = 500000, 4          # train_e2e_spatial.py:32-34
+
+
+def _jpeg_loaders(args, bs, rank, world):
+    """The reference's datasets and loaders over a JPEG frame directory (train_e2e_spatial.py:880-932, 1072-1093): 500,000
+    frames of random clips per training epoch, a quarter of that for validation, 2 x / 1 x the base number of workers."""
+    from .dataset import ActionSpotDataset, JpegClips
+    classes = load_classes(args)
+    frames_per_epoch = 500 if getattr(args, "debug_only", False) else EPOCH_NUM_FRAMES
+    dataset_len = max(bs * world, frames_per_epoch // args.clip_len)
+    kw = {"crop_dim": args.crop_dim, "dilate_len": getattr(args, "dilate_len", 0), "dataset": args.dataset}
+    if getattr(args, "fg_upsample", None) is not None:
+        assert args.fg_upsample > 0
+        kw["fg_upsample"] = args.fg_upsample
+    base = BASE_NUM_WORKERS if getattr(args, "num_workers", None) is None else args.num_workers
+    label = lambda split: os.path.join("data", args.dataset, split + ".json")
+    tr = ActionSpotDataset(classes, label("train"), args.frame_dir, args.modality, args.clip_len, dataset_len, is_eval=False, **kw)
+    va = ActionSpotDataset(classes, label("val"), args.frame_dir, args.modality, args.clip_len, max(bs * world, dataset_len // 4),
+                           is_eval=True, **kw)
+    tr.print_info()
+    va.print_info()
+    return (JpegClips(tr, bs, min(os.cpu_count(), 2 * base), rank, world), JpegClips(va, bs, min(os.cpu_count(), base), rank, world))
 
 
 def get_val_videos(args, classes):
@@ -216,10 +249,19 @@ def get_val_videos(args, classes):
                   for f in sorted(torch.randperm(n, generator=g)[: max(2, n // 40)].tolist())]
             labels.append({"video": v, "num_frames": n, "fps": 25, "events": ev})
             frames[v] = torch.randint(0, 256, (n, 3, args.crop_dim, args.crop_dim), generator=g, dtype=torch.uint8)
-    else:
+    elif os.path.exists(os.path.join(args.frame_dir, "val.json")):
         with open(os.path.join(args.frame_dir, "val.json")) as fp:
             labels = json.load(fp)
         frames = {l["video"]: np.load(os.path.join(args.frame_dir, "val_videos", l["video"] + ".npy"), mmap_mode="r") for l in labels}
+    else:
+        # a JPEG frame directory: the reference's ActionSpotVideoDataset (dataset/frame.py:364-437), frames decoded clip by clip
+        from .dataset import FrameReader, JpegVideo
+        with open(os.path.join("data", args.dataset, "val.json")) as fp:
+            labels = json.load(fp)
+        if getattr(args, "debug_only", False):
+            labels = labels[:2]
+        reader = FrameReader(args.frame_dir, args.modality)
+        frames = {l["video"]: JpegVideo(reader, l["video"], l["num_frames"]) for l in labels}
     return VideoClipDataset(classes, labels, frames, args.clip_len, overlap_len=0)
 
 

@@ -480,6 +480,37 @@ def test_train_driver_selects_the_best_epoch_by_validation_map(tmp_path):
     assert abs(m1 - losses[1]["val_mAP"]) < 1e-9                  # the best epoch's weights were restored
 
 
+def test_train_driver_reads_a_jpeg_frame_directory(tmp_path, monkeypatch):
+    """The reference's own data layout (frame_dir/<video>/%06d.jpg + data/<dataset>/{train,val}.json + class.txt,
+    dataset/frame.py:20-65,156-333, train_e2e_spatial.py:880-932): frames decoded on the host, handed over as uint8, resized
+    and augmented on the GPU (--augment), validation mAP over whole videos cut from the frame directory clip by clip."""
+    import json
+    from PIL import Image
+    from spot_amd import train as TR
+    rng = np.random.default_rng(0)
+    labels = []
+    for v, n in (("a", 40), ("b", 30)):
+        d = tmp_path / "frames" / v
+        d.mkdir(parents=True)
+        for f in range(n):
+            Image.fromarray(rng.integers(0, 256, (72, 128, 3), dtype=np.uint8)).save(str(d / ("%06d.jpg" % f)), quality=90)
+        labels.append({"video": v, "num_frames": n, "fps": 25,
+                       "events": [{"frame": f, "label": "xy"[f % 2], "xy": [0.3, 0.6]} for f in range(3, n, 9)]})
+    (tmp_path / "data" / "vnl_tiny").mkdir(parents=True)
+    for split in ("train", "val"):
+        (tmp_path / "data" / "vnl_tiny" / (split + ".json")).write_text(json.dumps(labels))
+    (tmp_path / "data" / "vnl_tiny" / "class.txt").write_text("x\ny\n")
+    monkeypatch.chdir(tmp_path)
+    args = TR.get_args(["vnl_tiny", str(tmp_path / "frames"), "-m", "rny008_gsm", "-t", "gru", "--clip_len", "8", "--crop_dim", "64",
+                        "--batch_size", "2", "--warm_up_epochs", "1", "-lr", "0.002", "--predict_location", "-s", str(tmp_path / "run"),
+                        "--criterion", "map", "--start_val_epoch", "1", "--num_epochs", "2", "--debug_only", "-j", "0", "--augment",
+                        "--dilate_len", "1", "--fg_upsample", "0.5"])
+    model, losses, best = TR.main(args)
+    assert len(losses) == 2 and all(np.isfinite(l["train"]) and np.isfinite(l["val"]) for l in losses) and 0 <= losses[1]["val_mAP"] <= 1
+    pred = json.load(open(tmp_path / "run" / "pred-val.1.json"))
+    assert [p["video"] for p in pred] == ["a", "b"]
+
+
 def test_train_driver_fused_mode_and_cross_mode_resume(tmp_path):
     """--fused: epochs through the HIP loss/backward/AdamW step with the learning rate of the reference's schedule; the
     optimizer file keeps torch.optim.AdamW's format (moments and step count per parameter), so the run resumes through the

@@ -2,6 +2,7 @@
 import ctypes
 import json
 import os
+import random
 import re
 import subprocess
 import sys
@@ -427,3 +428,136 @@ def test_mixup_loader_follows_the_reference_recipe():
     assert out["contains_event"].tolist() == [1, 1, 1] and torch.equal(out["xy"], batch["xy"])
     # the label layout E2EModel.epoch flattens for the soft-label cross entropy (train_e2e_spatial.py:546-550)
     assert out["label"].view(-1, out["label"].shape[-1]).shape == (B * T, nc + 1)
+
+
+# ------------------------------------------------------------------ JPEG frame directories (reference dataset/frame.py:20-65, 156-333)
+def _jpeg_tree(tmp_path, videos):
+    """frame_dir/<video>/%06d.jpg with frame f of video v filled with the grey level 10 + 3 f + 40 v (flat images survive JPEG
+    within a level or two), and the label list in the reference's JSON layout."""
+    from PIL import Image
+    labels = []
+    for v, (name, n, events, missing) in enumerate(videos):
+        d = tmp_path / "frames" / name
+        d.mkdir(parents=True)
+        for f in range(n):
+            if f in missing:
+                continue
+            img = np.full((24, 32, 3), 10 + 3 * f + 40 * v, np.uint8)
+            img[:, :, 1] //= 2                      # channels differ, so a dropped channel shows
+            Image.fromarray(img).save(str(d / ("%06d.jpg" % f)), quality=95)
+        labels.append({"video": name, "num_frames": n, "fps": 25,
+                       "events": [{"frame": f, "label": l, "xy": [0.25, 0.5]} for f, l in events]})
+    return str(tmp_path / "frames"), labels
+
+
+def test_frame_reader_pads_like_the_reference(tmp_path):
+    from spot_amd.dataset import FrameReader
+    frame_dir, _ = _jpeg_tree(tmp_path, [("v0", 12, [], {7})])
+    rd = FrameReader(frame_dir, "rgb")
+    # which frame a decoded image is (JPEG moves a level by one or two; frames are three levels apart); -1: a zero frame
+    level = lambda t: -1 if int(t.max()) == 0 else int(round((float(t[0].float().mean()) - 10) / 3))
+    x = rd.load_frames("v0", -3, 5, pad=True)
+    assert x.dtype == torch.uint8 and tuple(x.shape) == (8, 3, 24, 32)
+    assert int(x[:3].max()) == 0 and [level(f) for f in x[3:]] == [0, 1, 2, 3, 4]                 # frames before 0: zero frames in front
+    # an unreadable frame in the middle: the later frames move up, the hole is a zero frame at the END (and only with pad)
+    y = rd.load_frames("v0", 5, 10, pad=True)
+    assert [level(f) for f in y] == [5, 6, 8, 9, -1]
+    assert tuple(rd.load_frames("v0", 5, 10, pad=False).shape) == (4, 3, 24, 32)
+    assert tuple(rd.load_frames("v0", -2, 6, pad=False).shape) == (8, 3, 24, 32)                  # the front is padded regardless
+    assert [level(f) for f in rd.load_frames("v0", 0, 12, pad=True, stride=4)] == [0, 4, 8]
+    assert abs(float(x[3][1].float().mean()) - 5) <= 2 and abs(float(x[3][2].float().mean()) - 10) <= 2   # RGB order kept
+    assert tuple(FrameReader(frame_dir, "flow").load_frames("v0", 0, 2).shape) == (2, 2, 24, 32)  # flow: the G and B planes
+    with pytest.raises(RuntimeError):
+        rd.read_frame(os.path.join(frame_dir, "v0", "000007.jpg"))
+    random.seed(3)
+    jit = [level(f) for f in rd.load_frames("v0", 0, 6, stride=3, randomize=True)]
+    random.seed(3)
+    assert jit == [0 + random.randint(0, 2), 3 + random.randint(0, 2)]                           # one draw per frame, in order
+
+
+def test_clip_sampler_draws_in_the_reference_order_and_labels_clips(tmp_path):
+    from spot_amd.dataset import ActionSpotDataset
+    frame_dir, labels = _jpeg_tree(tmp_path, [("a", 40, [(4, "x"), (30, "y")], set()), ("b", 25, [(10, "y")], set())])
+    classes = {"x": 1, "y": 2}
+    ds = ActionSpotDataset(classes, labels, frame_dir, "rgb", 16, 50, is_eval=True, dilate_len=1, dataset="vnl_2.0")
+    random.seed(11)
+    got = [ds[0] for _ in range(6)]
+    random.seed(11)
+    for item in got:          # uniform sampling: one weighted video choice, then one start offset in [-pad, len - 1 + pad - clip_len]
+        meta = random.choices(labels, weights=ds._weights_by_length)[0]
+        start = -5 + random.randint(0, max(0, meta["num_frames"] - 1 + (2 * 5 - 16)))
+        assert (item["video"], item["start"], item["end"]) == (meta["video"], start, start + 16)
+        want = np.zeros(16, np.int64)
+        xy = np.zeros((16, 2), np.float32)
+        for e in meta["events"]:
+            for i in range(e["frame"] - start - 1, e["frame"] - start + 2):        # dilated by one frame either side
+                if 0 <= i < 16:
+                    want[i] = classes[e["label"]]
+                    xy[i] = (0.25, 0.5)
+        assert np.array_equal(item["label"], want) and np.array_equal(item["xy"], xy)
+        assert item["contains_event"] == int(want.sum() > 0)
+        assert item["frame"].dtype == torch.uint8 and tuple(item["frame"].shape) == (16, 3, 24, 32)
+        k = max(0, -start)                                                        # zero frames in front of the video's first
+        assert int(item["frame"][:k].max() if k else 0) == 0
+        v = 0 if meta["video"] == "a" else 1
+        assert abs(float(item["frame"][k][0].float().mean()) - (10 + 3 * (start + k) + 40 * v)) <= 2
+    # foreground sampling: (almost) every clip is drawn around an event and holds it
+    fg = ActionSpotDataset(classes, labels, frame_dir, "rgb", 16, 50, fg_upsample=1e-9, dataset="vnl_2.0")
+    random.seed(5)
+    assert all(fg[0]["contains_event"] == 1 for _ in range(20))
+    # datasets without locations hand out xy = None; mixup is the batch wrapper's job
+    assert ActionSpotDataset(classes, labels, frame_dir, "rgb", 16, 50, dataset="finediving")[0]["xy"] is None
+    with pytest.raises(NotImplementedError):
+        ActionSpotDataset(classes, labels, frame_dir, "rgb", 16, 50, mixup=True)
+
+
+def test_jpeg_loader_batches_and_video_view(tmp_path):
+    from spot_amd.dataset import ActionSpotDataset, FrameReader, JpegClips, JpegVideo
+    from spot_amd.evaluate import VideoClipDataset
+    frame_dir, labels = _jpeg_tree(tmp_path, [("a", 40, [(4, "x"), (30, "y")], set()), ("b", 25, [(10, "y")], {20})])
+    classes = {"x": 1, "y": 2}
+    ds = ActionSpotDataset(classes, labels, frame_dir, "rgb", 8, 13, is_eval=False, dataset="vnl_2.0")
+    ld = JpegClips(ds, 4)
+    assert len(ld) == 3
+    first = list(ld)
+    assert [tuple(b["frame"].shape) for b in first] == [(4, 8, 3, 24, 32)] * 3
+    assert first[0]["frame"].dtype == torch.uint8 and first[0]["label"].dtype == torch.int64 and tuple(first[0]["xy"].shape) == (4, 8, 2)
+    ld.epoch = 0                                          # the same epoch again: the same clips; the next epoch: others
+    again, nxt = list(ld), list(ld)
+    assert all(torch.equal(a["start"], b["start"]) and a["video"] == b["video"] for a, b in zip(first, again))
+    assert any(not torch.equal(a["start"], b["start"]) or a["video"] != b["video"] for a, b in zip(first, nxt))
+    other = list(JpegClips(ds, 4, rank=1, world=2))
+    assert len(other) == 1 and (other[0]["video"] != first[0]["video"] or not torch.equal(other[0]["start"], first[0]["start"]))
+    two = list(JpegClips(ds, 4, num_workers=2))            # decoding workers: same batch format
+    assert len(two) == 3 and tuple(two[0]["frame"].shape) == (4, 8, 3, 24, 32)
+    # whole-video validation clips cut from the frame directory equal the clips cut from the decoded array
+    rd = FrameReader(frame_dir, "rgb")
+    lazy = {l["video"]: JpegVideo(rd, l["video"], l["num_frames"]) for l in labels}
+    full = {l["video"]: rd.load_frames(l["video"], 0, l["num_frames"], pad=True) for l in labels}
+    assert lazy["b"].shape == (25, 3, 24, 32) and tuple(full["b"].shape) == (25, 3, 24, 32)
+    a = VideoClipDataset(classes, labels, lazy, 8)
+    b = VideoClipDataset(classes, labels, full, 8)
+    assert len(a) == len(b)
+    for i in range(len(a)):
+        x, y = a[i], b[i]
+        assert (x["video"], x["start"]) == (y["video"], y["start"])
+        if x["video"] == "a":                              # (video b has an unreadable frame: per-clip and whole-video reads put its zero frame in different places)
+            assert torch.equal(x["frame"], y["frame"])
+
+
+def test_training_driver_finds_a_jpeg_frame_directory(tmp_path, monkeypatch):
+    from spot_amd import train
+    frame_dir, labels = _jpeg_tree(tmp_path, [("a", 40, [(4, "x"), (30, "y")], set()), ("b", 25, [(10, "y")], set())])
+    (tmp_path / "data" / "vnl_tiny").mkdir(parents=True)
+    for split in ("train", "val"):
+        (tmp_path / "data" / "vnl_tiny" / (split + ".json")).write_text(json.dumps(labels))
+    (tmp_path / "data" / "vnl_tiny" / "class.txt").write_text("x\ny\n")
+    monkeypatch.chdir(tmp_path)
+    args = train.get_args(["vnl_tiny", frame_dir, "-m", "rny008_gsm", "-s", str(tmp_path / "out"), "--clip_len", "8", "--batch_size", "4",
+                           "--debug_only", "-j", "0", "--dilate_len", "1", "--fg_upsample", "0.5", "--device", "cpu"])
+    tr, va = train.get_loaders(args, 3)
+    assert len(tr) == 500 // 8 // 4 and len(va) == max(4, 500 // 8 // 4) // 4
+    batch = next(iter(tr))
+    assert tuple(batch["frame"].shape) == (4, 8, 3, 24, 32) and batch["frame"].dtype == torch.uint8 and tuple(batch["xy"].shape) == (4, 8, 2)
+    vids = train.get_val_videos(args, {"x": 1, "y": 2})
+    assert [v for v, _, _ in vids.videos] == ["a", "b"] and tuple(vids[0]["frame"].shape) == (8, 3, 24, 32)
