@@ -96,7 +96,7 @@ def run_inference(model, frames, classes, clip_len, batch_size=16, postprocess=T
     if gather is not None:                      # multi-rank: disjoint frame ranges, sum on the host
         acc.scores, acc.support, acc.locations = gather(acc.scores, acc.support, acc.locations)
     scores, locations = acc.finish()
-    pred_events = [{"video": video, "events": events_from_scores(scores, locations, classes)}]
+    pred_events = [{"video": video, "events": events_from_scores(scores, locations, classes, min_score=0.15 if postprocess else None)}]
     if postprocess:
         pred_events = filter_events_by_score(pred_events, fg_threshold=0.15)
         pred_events = non_max_suppression_events(pred_events, 3)

@@ -30,11 +30,15 @@ class ScoreAccumulator:
         return self.scores, self.locations
 
 
-def events_from_scores(scores: np.ndarray, locations: np.ndarray, classes):
-    """argmax != background -> event (inference_on_mp4.py:247-262)."""
+def events_from_scores(scores: np.ndarray, locations: np.ndarray, classes, min_score=None):
+    """argmax != background -> event (inference_on_mp4.py:247-262).  min_score: leave out events the score filter that follows
+    (filter_events_by_score with the same threshold) would drop anyway, so that no dict is built for them."""
     pred = np.argmax(scores, axis=1)
     idx = np.nonzero(pred)[0]                       # only the foreground frames are visited (a few per cent of a video)
     cls = pred[idx]
+    if min_score is not None:
+        keep = scores[idx, cls].astype(np.float64) >= min_score      # (in double, as the filter compares the Python floats)
+        idx, cls = idx[keep], cls[keep]
     return [{"label": classes[c - 1], "frame": i, "score": s, "xy": xy}
             for i, c, s, xy in zip(idx.tolist(), cls.tolist(), scores[idx, cls].tolist(), locations[idx].tolist())]
 
