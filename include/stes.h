@@ -379,6 +379,10 @@ int stes_col_stats(const uint16_t* X, int64_t ldx, int ncols, int64_t M, float* 
                    void* stream);
 /* TemporalShift.shift, reference model/shift.py:37-52 (out of place; backward = adjoint shift). */
 int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C, int B, int T, int H, int W, int backward, void* stream);
+/* The same shift in place, as the reference's module does it (model/shift.py:55-66: the block input itself is shifted, so the
+ * shortcut and the ReLU mask of the layer in front see the shifted tensor).  Only the 2 * fold channels that move are touched.
+ * fold and C multiples of 4. */
+int stes_tsm_shift_inplace(uint16_t* X, int fold, int C, int B, int T, int H, int W, int backward, void* stream);
 
 /* ---------------------------------------------------- temporal head, loss, optimiser ----
  * Bidirectional GRU layer (torch.nn.GRU inside GRUPrediction, reference model/modules.py:20-36).

@@ -1167,6 +1167,37 @@ __global__ __launch_bounds__(256) void tsm_shift_kernel(const bf16* __restrict__
     }
 }
 
+// The same shift in place, touching only the 2 * fold channels that move (a quarter of the tensor at fold = C / 8).  A thread
+// owns four channels of one pixel of one clip and walks the clip's frames in the direction its values come from, eight frames
+// per trip with all loads of a trip ahead of its stores: a value is read before the trip that overwrites it.
+constexpr int TSM_TRIP = 8;
+__global__ __launch_bounds__(256) void tsm_shift_inplace_kernel(bf16* X, int fold, int C, int T, long plane, long items, int chunks, int dir) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= items) return;
+    const long bp = i / chunks;                       // clip * plane + pixel
+    const int q = (int)(i - bp * chunks);
+    const long b = bp / plane, px = bp - b * plane;
+    const int step = (4 * q < fold ? 1 : -1) * dir;   // out[t] = in[t + step]
+    const long fstride = plane * C;                   // elements between frames
+    bf16* base = X + (b * T * plane + px) * C + 4 * q;
+    // walk u = 0 .. T-1 over frames t(u) = step > 0 ? u : T-1-u, so that the source of t(u) is always t(u + 1)
+    const long first = step > 0 ? 0 : (long)(T - 1) * fstride;
+    const long adv = step > 0 ? fstride : -fstride;
+    for (int u0 = 0; u0 < T; u0 += TSM_TRIP) {
+        u32x2 v[TSM_TRIP];
+#pragma unroll
+        for (int k = 0; k < TSM_TRIP; ++k) {
+            const int us = u0 + k + 1;                // the source position of u0 + k
+            v[k] = (u32x2){0u, 0u};
+            if (us < T) v[k] = *reinterpret_cast<const u32x2*>(base + first + us * adv);
+        }
+#pragma unroll
+        for (int k = 0; k < TSM_TRIP; ++k)
+            if (u0 + k < T) *reinterpret_cast<u32x2*>(base + first + (u0 + k) * adv) = v[k];
+    }
+}
+
 int flat_blocks(long total, int tpb, int ncols) {
     int a = ncols, b = tpb;
     while (b) { int t = a % b; a = b; b = t; }
@@ -1398,6 +1429,20 @@ extern "C" int stes_tsm_shift(const uint16_t* X, uint16_t* out, int fold, int C,
     long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(tsm_shift_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16*)X, (bf16*)out, fold, C, T, plane, M,
                        backward ? -1 : 1);
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_tsm_shift_inplace(uint16_t* X, int fold, int C, int B, int T, int H, int W, int backward, void* stream) {
+    STES_CHECK(X && fold >= 0 && 2 * fold <= C && B > 0 && T > 0 && H > 0 && W > 0, STES_ERR_ARG, "stes_tsm_shift_inplace: bad argument");
+    STES_CHECK(fold % 4 == 0 && C % 4 == 0, STES_ERR_UNSUPPORTED, "stes_tsm_shift_inplace: fold and C must be multiples of 4 (8-byte pieces)");
+    if (fold == 0) return STES_OK;
+    const long plane = (long)H * W;
+    const int chunks = 2 * fold / 4;
+    const long items = (long)B * plane * chunks;
+    STES_CHECK((items + 255) / 256 <= 0x7fffffffL, STES_ERR_UNSUPPORTED, "stes_tsm_shift_inplace: tensor too large");
+    hipLaunchKernelGGL(tsm_shift_inplace_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, S(stream), (bf16*)X, fold, C, T, plane,
+                       items, chunks, backward ? -1 : 1);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

@@ -143,7 +143,10 @@ class Block:
             self.G = a(nm + ".G", self.Mi * self.fold, BF)
             self.gate = a(nm + ".gate", self.Mi * 2, F32)
         elif self.kind == "tsm":
-            self.Xs = a(nm + ".Xs", self.Mi * self.cin, BF)
+            # the reference shifts the block input in place (model/shift.py:55-66): nobody reads the unshifted tensor afterwards,
+            # so only the moving quarter of the channels is touched; other fold widths go through a shifted copy
+            self.tsm_inplace = self.tsm_fold % 4 == 0 and self.cin % 4 == 0
+            self.Xs = None if self.tsm_inplace else a(nm + ".Xs", self.Mi * self.cin, BF)
         # (X > 0) as one bit per element, written by the kernel that produces X and read by this block's input gradient in
         # place of X; the plain temporal shift masks with the shifted tensor instead (model/shift.py:55-66)
         self.xbits = a(nm + ".xbits", self.Mi * self.cin // 8, torch.uint8) if train and self.kind != "tsm" else None
@@ -186,8 +189,11 @@ class Block:
                 lib.call("stes_gsm_shift", p(self.Xc), p(self.gate), p(self.G), C.byref(geom))
             a0, k0 = self.G, self.fold
         elif self.kind == "tsm":
-            lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
-            a_src = self.Xs
+            if self.tsm_inplace:
+                lib.call("stes_tsm_shift_inplace", p(X), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
+            else:
+                lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
+                a_src = self.Xs
         self.a_src = a_src
         if (not train and e.block_fused and self.kind == "gsm" and cin == cmid == cout
                 and lib.block_eval_takes(cmid, self.Hi, self.Wi, self.rd, self.fold, self.stride, self.down)):
@@ -363,9 +369,12 @@ class Block:
             dXf = sc("gsm.dXf", Mi * fold)
             lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(self.gate), p(dxbn), p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
         elif self.kind == "tsm":
-            dY1s = sc("tsm.dY1s", Mi * cin)
-            lib.call("stes_tsm_shift", p(dY1), p(dY1s), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
-            dY1 = dY1s
+            if self.tsm_inplace:
+                lib.call("stes_tsm_shift_inplace", p(dY1), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
+            else:
+                dY1s = sc("tsm.dY1s", Mi * cin)
+                lib.call("stes_tsm_shift", p(dY1), p(dY1s), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
+                dY1 = dY1s
         # --- shortcut
         if self.down:
             bnd = self.bnd

@@ -130,6 +130,7 @@ _SIGS = {
     "stes_gsm_bwd_conv": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "stes_col_stats": [_P, _I64, _I32, _I64, _P, _P, _P, _P],
     "stes_tsm_shift": [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stes_tsm_shift_inplace": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stes_gru_forward": [_P, _P],
     "stes_gru_backward": [_P, _P],
     "stes_gru_forward_noalloc": [_P, _P],

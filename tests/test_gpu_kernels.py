@@ -241,6 +241,22 @@ def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
         lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
 
 
+@pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 3, 4, 32, 4), (1, 8, 2, 2, 64, 8), (3, 19, 1, 5, 320, 40), (1, 1, 2, 3, 32, 4), (2, 64, 7, 7, 768, 96)])
+def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
+    """The temporal shift (reference model/shift.py:37-52) applied in place -- only the moving channels are touched, frames walked
+    in the direction the values come from -- against the out-of-place kernel, forward and adjoint, bit for bit."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(B * 100 + T)
+    X = dev(bfr(B * T * H * W, Cc, g=g))
+    for backward in (0, 1):
+        ref = torch.empty_like(X)
+        lib.call("stes_tsm_shift", lib.ptr(X), lib.ptr(ref), fold, Cc, B, T, H, W, backward)
+        Y = X.clone()
+        lib.call("stes_tsm_shift_inplace", lib.ptr(Y), fold, Cc, B, T, H, W, backward)
+        torch.cuda.synchronize()
+        assert torch.equal(Y.view(torch.int16), ref.view(torch.int16)), backward
+
+
 @pytest.mark.parametrize("N,with_slice", [(43, True), (300, False)])
 def test_block_eval_s3_equals_the_kernel_sequence(N, with_slice):
     """A stage-3 bottleneck's evaluation forward in one kernel against the sequence it replaces (stes_gemm with the gated-shift
