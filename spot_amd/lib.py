@@ -61,6 +61,13 @@ BlockEvalArgs = _struct("BlockEvalArgs", [
     ("out", _P), ("slice", _P), ("slice_n", _I32),
     ("N", _I32), ("H", _I32), ("W", _I32), ("C", _I32), ("rd", _I32), ("fold", _I32)])
 
+BlockFrontArgs = _struct("BlockFrontArgs", [
+    ("X", _P), ("G", _P), ("fold", _I32),
+    ("W1", _P), ("s1", _P), ("b1", _P),
+    ("wp2", _P), ("s2", _P), ("b2", _P),
+    ("c2", _P), ("pooled", _P),
+    ("N", _I32), ("H", _I32), ("W", _I32), ("Cin", _I32), ("Cmid", _I32)])
+
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
     ("q_scale", _P), ("q_shift", _P), ("q_relu", _I32), ("q_gate", _P), ("gate_group", _I32),
@@ -96,6 +103,7 @@ _SIGS = {
     "stes_wgrad": [_P, _P],
     "stes_gemm_small2": [_P, _P],
     "stes_block_eval_s3": [_P, _P],
+    "stes_block_front_eval": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
@@ -436,6 +444,28 @@ def gemm2(A, W1, H, W2, Cout, M, K1, N1, N2, *, bias1=None, act1=0, relu_mask1=N
     fn = lambda: check(lib().stes_gemm_small2(C.byref(a), stream()), "stes_gemm_small2")
     if TIMING is not None:
         _timed("gemm_small2_kernel", 2 * M * (K1 + N1) + 2 * N1 * (K1 + N2) + M * N2 * (4 if a.c_f32 else 2), 2 * M * N1 * (K1 + N2), fn)
+        return
+    fn()
+
+
+def block_front_takes(cin, cmid, H, W, stride, fold):
+    """Shapes for which stes_block_front_eval runs conv1 -> bn/act -> strided conv2 (+ squeeze) of a bottleneck in one kernel
+    (the rule in stes_block_front.hip: RegNet-Y 800MF's s1.b1 and s2.b1)."""
+    return stride == 2 and H == W and (cin, cmid, W) in ((32, 64, 112), (64, 128, 56)) and fold % 8 == 0 and fold <= 32
+
+
+def block_front(X, G, fold, W1, bn1, wp2, bn2, c2, pooled, N, H, W, cin, cmid):
+    """conv1 + bn1/ReLU + strided grouped conv2 + squeeze of a strided bottleneck in evaluation mode; see stes_block_front_eval."""
+    a = BlockFrontArgs()
+    a.X, a.G, a.fold = ptr(X), ptr(G), fold
+    a.W1, a.s1, a.b1 = ptr(W1), ptr(bn1[0]), ptr(bn1[1])
+    a.wp2, a.s2, a.b2 = ptr(wp2), ptr(bn2[0]), ptr(bn2[1])
+    a.c2, a.pooled = ptr(c2), ptr(pooled)
+    a.N, a.H, a.W, a.Cin, a.Cmid = N, H, W, cin, cmid
+    fn = lambda: check(lib().stes_block_front_eval(C.byref(a), stream()), "stes_block_front_eval")
+    if TIMING is not None:
+        m = N * H * W
+        _timed("block_front_kernel<%d, %d, %d>" % (cin, cmid, W), 2 * m * cin + 2 * (m // 4) * cmid, 2 * m * cin * cmid + 2 * (m // 4) * cmid * 144, fn)
         return
     fn()
 
