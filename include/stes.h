@@ -96,10 +96,10 @@ typedef struct {
 } stes_gemm_args;
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
-/* Evaluation forward of the front half of a strided bottleneck of stages 1 and 2 of RegNet-Y 800MF (112 x 112 x 32 -> 64 channels
- * -> 56 x 56, and 56 x 56 x 64 -> 128 channels -> 28 x 28) in ONE kernel: conv1 (1x1, the gated shift's result G in place of the
- * first `fold` input channels, reference model/shift.py:157-161; fold may be 0) -> bn1 + ReLU -> grouped 3x3 conv2 with stride 2
- * -> raw c2 [N*(H/2)*(W/2)][Cmid] and the squeeze-excite squeeze pooled [N][Cmid] = mean relu(bn2(c2)) (timm Bottleneck,
+/* Evaluation forward of the front half of a bottleneck of stages 1 and 2 of RegNet-Y 800MF (stride 2: 112 x 112 x 32 -> 64 channels
+ * -> 56 x 56, and 56 x 56 x 64 -> 128 channels -> 28 x 28; stride 1: 28 x 28 x 128 -> 128 channels) in ONE kernel: conv1 (1x1, the
+ * gated shift's result G in place of the first `fold` input channels, reference model/shift.py:157-161; fold may be 0) -> bn1 +
+ * ReLU -> grouped 3x3 conv2 with the given stride -> raw c2 [N*(H/stride)*(W/stride)][Cmid] and the squeeze-excite squeeze pooled [N][Cmid] = mean relu(bn2(c2)) (timm Bottleneck,
  * train_e2e_spatial.py:305-314; evaluation-mode BatchNorms).  conv1's output, at the block's input resolution the largest tensor
  * of the network, stays on chip.  Same roundings and outputs as stes_gemm followed by stes_conv3x3g_fwd_pool.
  * X [N*H*W][Cin]; G [N*H*W][fold]; W1 [Cmid][Cin] bf16 (fold-permuted columns as stes_gemm takes them); wp2: stes_pack_conv3x3g's
@@ -109,7 +109,7 @@ typedef struct {
     const uint16_t* W1; const float* s1; const float* b1;
     const uint16_t* wp2; const float* s2; const float* b2;
     uint16_t* c2; uint16_t* pooled;
-    int32_t N, H, W, Cin, Cmid;
+    int32_t N, H, W, Cin, Cmid, stride;
 } stes_block_front_args;
 int stes_block_front_eval(const stes_block_front_args* a, void* stream);
 

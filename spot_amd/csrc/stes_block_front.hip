@@ -1,11 +1,12 @@
-// Evaluation forward of the front half of a strided bottleneck of stages 1 and 2 (RegNet-Y 800MF s1.b1: 112 x 112 x 32 -> 64
-// channels -> 56 x 56; s2.b1: 56 x 56 x 64 -> 128 channels -> 28 x 28) in one kernel: conv1 (1x1, with the gated shift's result
-// G substituted for the first `fold` input channels, model/shift.py:157-161) -> bn1 + ReLU -> grouped 3x3 conv2 with stride 2
+// Evaluation forward of the front half of a bottleneck of stages 1 and 2 (RegNet-Y 800MF s1.b1: 112 x 112 x 32 -> 64 channels
+// -> 56 x 56; s2.b1: 56 x 56 x 64 -> 128 channels -> 28 x 28; s2.b2 / s2.b3: 28 x 28 x 128 -> 128 channels, stride 1) in one kernel: conv1 (1x1, with the gated shift's result
+// G substituted for the first `fold` input channels, model/shift.py:157-161) -> bn1 + ReLU -> grouped 3x3 conv2 (stride 2 or 1)
 // -> raw c2 and the squeeze-excite squeeze mean_hw relu(bn2(c2)) (timm Bottleneck as the reference builds it,
 // train_e2e_spatial.py:305-314; BatchNorms in evaluation mode).  conv1 runs at the block's INPUT resolution, so its output is
 // the largest tensor of the network (1.6 GB per 1,024 frames in s1.b1): as separate kernels it is written once and read once
 // only to be reduced four to one by the strided convolution.  Here it never leaves the chip.
-//   One workgroup (4 waves) walks an image's output rows.  Per output row ro:
+//   One workgroup (4 waves) walks an image's output rows.  Per output row ro (described for stride 2; with stride 1 a step
+//   brings one new row and the lanes' pixels are one apart):
 //   (a) the two new conv1 rows 2ro and 2ro+1: pixels x channels products on MFMA (weights in registers for the whole launch,
 //       pixel fragments straight from memory, fetched one output row ahead), rounded to bf16 as the kernel sequence stores
 //       them, bn1 + ReLU, into a ring of four row slots in LDS (row 2ro-1 is there from the step before; row -1 is zeros);
@@ -35,38 +36,43 @@ __device__ __forceinline__ f_s16x4 bf_tap_frag(const bf16* __restrict__ wp, int 
     return *reinterpret_cast<const f_s16x4*>(wp + (((long)g * 5 + (slot >> 1)) * 64 + packed_lane) * 8 + 4 * (q & 1));
 }
 
-template <int CIN, int CMID, int WI>
+// STRIDE: conv2's stride (2: the first block of a stage, 1: the others); NSPLIT: conv1's output channels are dealt to this many
+// wave groups (2 where a row has too few pixel tiles to occupy four waves)
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
 struct FrontShape {
-    static constexpr int NT = CMID / 16, KS = CIN / 32, WO = WI / 2, CT = (WI + 15) / 16, CF = (WO + 15) / 16;
-    static constexpr int PXS = CMID + 4;                   // ring: elements per pixel (8 bytes of padding)
+    static constexpr int NT = CMID / 16, NTW = NT / NSPLIT, KS = CIN / 32, WO = WI / STRIDE, CT = (WI + 15) / 16, CF = (WO + 15) / 16;
+    // ring: elements per pixel; the padding puts two lanes' pixels (STRIDE pixels apart) four banks apart for the 8-byte reads
+    static constexpr int PXS = CMID + (STRIDE == 2 ? 4 : 8);
     static constexpr int SLOT = (WI + 2) * PXS;            // a row slot with a zero pixel either side
     static constexpr int SPX = CMID + 8;                   // staging row: elements per pixel (16-byte chunks stay aligned)
     static constexpr int GPW = CMID / 64;                  // 16-channel groups per wave
-    static constexpr int TILES = 2 * CT, TPW = (TILES + 3) / 4;
+    static constexpr int UNITS = STRIDE * CT * NSPLIT, UPW = (UNITS + 3) / 4;      // (pixel tile, channel share) units of a step
     static constexpr size_t LDS = (size_t)(4 * SLOT + WO * SPX) * 2 + 4 * CMID * sizeof(float);
+    static_assert(NT % NSPLIT == 0 && (NSPLIT == 1 || NSPLIT == 2), "channel shares");
 };
 
-template <int CIN, int CMID, int WI>
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_front_args p) {
-    typedef FrontShape<CIN, CMID, WI> S;
+    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT> S;
     extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
     bf16* ring = reinterpret_cast<bf16*>(bf_smem);                          // [4][SLOT]
     bf16* stage = ring + 4 * S::SLOT;                                       // [WO][SPX]
     float* cst = reinterpret_cast<float*>(stage + S::WO * S::SPX);
     float* s1 = cst, *b1 = cst + CMID, *s2 = cst + 2 * CMID, *b2 = cst + 3 * CMID;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int HI = p.H, HO = HI / 2, fold = p.fold;
+    const int HI = p.H, HO = HI / STRIDE, fold = p.fold;
     const bf16* __restrict__ X = (const bf16*)p.X;
     const bf16* __restrict__ G = (const bf16*)p.G;
     for (int i = tid; i < CMID; i += 256) { s1[i] = p.s1[i]; b1[i] = p.b1[i]; s2[i] = p.s2[i]; b2[i] = p.b2[i]; }
     for (int i = tid; i < 4 * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // borders stay zero for good
-    // conv1's weights: fragment (j, ks) = output channels 16j.., input channels 32ks..
-    bf16x8 wf[S::NT][S::KS];
+    // conv1's weights of this wave's channel share: fragment (j, ks) = output channels 16 (nt0 + j).., input channels 32ks..
+    const int nt0 = (wave % NSPLIT) * S::NTW;
+    bf16x8 wf[S::NTW][S::KS];
 #pragma unroll
-    for (int j = 0; j < S::NT; ++j)
+    for (int j = 0; j < S::NTW; ++j)
 #pragma unroll
         for (int ks = 0; ks < S::KS; ++ks)
-            wf[j][ks] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)(16 * j + fr) * CIN + 32 * ks + 8 * fq);
+            wf[j][ks] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)(16 * (nt0 + j) + fr) * CIN + 32 * ks + 8 * fq);
     // conv2's taps of this wave's groups
     f_s16x4 wA[S::GPW][3][3];
 #pragma unroll
@@ -82,17 +88,21 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
         // a pixel fragment of conv1's input: row r, column tile ct, k-step ks (the first `fold` channels come from G)
         auto load_a = [&](int r, int ct, int ks) -> bf16x8 {
             const int px = min(16 * ct + fr, WI - 1), k = 32 * ks + 8 * fq;
-            const long pix = img + (long)r * WI + px;
+            const long pix = img + (long)(STRIDE == 1 ? min(r, HI - 1) : r) * WI + px;
             const bf16* src = k < fold ? G + pix * fold + k : X + pix * CIN + k;
             return *reinterpret_cast<const bf16x8*>(src);
         };
-        bf16x8 af[S::TPW][S::KS];
+        // the conv1 rows a step brings: stride 2: rows 2ro and 2ro+1; stride 1: row ro+1 (row 0 comes from a step -1 that has no
+        // convolution; the row below the image is zeros)
+        const int ro_first = STRIDE == 2 ? 0 : -1;
+        auto unit_row = [&](int ro, int u) { return STRIDE == 2 ? 2 * ro + (u / NSPLIT) / S::CT : ro + 1; };
+        bf16x8 af[S::UPW][S::KS];
 #pragma unroll
-        for (int i = 0; i < S::TPW; ++i) {
-            const int ti = wave + 4 * i;
-            if (ti < S::TILES) {
+        for (int i = 0; i < S::UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < S::UNITS) {
 #pragma unroll
-                for (int ks = 0; ks < S::KS; ++ks) af[i][ks] = load_a(ti / S::CT, ti % S::CT, ks);
+                for (int ks = 0; ks < S::KS; ++ks) af[i][ks] = load_a(unit_row(ro_first, u), (u / NSPLIT) % S::CT, ks);
             }
         }
         // row -1 of the image: zeros (the slot is reused by rows 3, 7, ..)
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
         __syncthreads();
 
 #pragma unroll 1
-        for (int ro = 0; ro <= HO; ++ro) {
+        for (int ro = ro_first; ro <= HO; ++ro) {
             // the staged output row of the step before leaves as whole chunks
             if (ro > 0) {
                 bf16* dst = (bf16*)p.c2 + ((long)n * HO + (ro - 1)) * S::WO * CMID;
@@ -118,29 +128,30 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
                 }
             }
             if (ro == HO) break;
-            // (a) conv1 rows 2ro and 2ro+1 into their ring slots (row r lives in slot (r + 1) & 3)
+            // (a) the step's new conv1 rows into their ring slots (row r lives in slot (r + 1) & 3; a row below the image is zeros)
 #pragma unroll
-            for (int i = 0; i < S::TPW; ++i) {
-                const int ti = wave + 4 * i;
-                if (ti >= S::TILES) continue;
-                const int r = 2 * ro + ti / S::CT, ct = ti % S::CT;
-                f32x4 acc[S::NT];
+            for (int i = 0; i < S::UPW; ++i) {
+                const int u = wave + 4 * i;
+                if (u >= S::UNITS) continue;
+                const int r = unit_row(ro, u), ct = (u / NSPLIT) % S::CT;
+                f32x4 acc[S::NTW];
 #pragma unroll
-                for (int j = 0; j < S::NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < S::NTW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < S::KS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < S::NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[j], 0, 0, 0);
+                    for (int j = 0; j < S::NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[j], 0, 0, 0);
                 const int px = 16 * ct + fr;
                 if (px < WI) {
-                    bf16* dstp = ring + ((r + 1) & 3) * S::SLOT + (px + 1) * S::PXS + 4 * fq;
+                    bf16* dstp = ring + ((r + 1) & 3) * S::SLOT + (px + 1) * S::PXS + 16 * nt0 + 4 * fq;
+                    const bool inside = STRIDE == 2 || r < HI;
 #pragma unroll
-                    for (int j = 0; j < S::NT; ++j) {
+                    for (int j = 0; j < S::NTW; ++j) {
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int ch = 16 * j + 4 * fq + e;
-                            o[e] = (bf16)fmaxf((float)(bf16)acc[j][e] * s1[ch] + b1[ch], 0.f);
+                            const int ch = 16 * (nt0 + j) + 4 * fq + e;
+                            o[e] = inside ? (bf16)fmaxf((float)(bf16)acc[j][e] * s1[ch] + b1[ch], 0.f) : (bf16)0.f;
                         }
                         *reinterpret_cast<bf16x4*>(dstp + 16 * j) = o;
                     }
@@ -149,16 +160,17 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
             // the next step's pixel fragments are requested now and arrive during (b)
             if (ro + 1 < HO) {
 #pragma unroll
-                for (int i = 0; i < S::TPW; ++i) {
-                    const int ti = wave + 4 * i;
-                    if (ti < S::TILES) {
+                for (int i = 0; i < S::UPW; ++i) {
+                    const int u = wave + 4 * i;
+                    if (u < S::UNITS) {
 #pragma unroll
-                        for (int ks = 0; ks < S::KS; ++ks) af[i][ks] = load_a(2 * ro + 2 + ti / S::CT, ti % S::CT, ks);
+                        for (int ks = 0; ks < S::KS; ++ks) af[i][ks] = load_a(unit_row(ro + 1, u), (u / NSPLIT) % S::CT, ks);
                     }
                 }
             }
             __syncthreads();
-            // (b) output row ro: source rows 2ro-1, 2ro, 2ro+1 = slots (2ro + a) & 3
+            if (ro < 0) continue;                                           // (stride 1: the step that only brings row 0)
+            // (b) output row ro: source rows STRIDE ro - 1 + a = slots (STRIDE ro + a) & 3
 #pragma unroll
             for (int gi = 0; gi < S::GPW; ++gi) {
                 const int g = wave + 4 * gi, ch0 = g * 16 + 4 * fq;
@@ -167,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
                 for (int f = 0; f < S::CF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const bf16* row = ring + ((2 * ro + a) & 3) * S::SLOT + ch0;
+                    const bf16* row = ring + ((STRIDE * ro + a) & 3) * S::SLOT + ch0;
 #pragma unroll
                     for (int b = 0; b < 3; ++b)
 #pragma unroll
                         for (int f = 0; f < S::CF; ++f) {
-                            const int pxi = min(2 * (16 * f + fr) + b, WI + 1);      // ring pixel index of column 2co + b - 1
+                            const int pxi = min(STRIDE * (16 * f + fr) + b, WI + 1);      // ring pixel index of column STRIDE co + b - 1
                             const f_u32x2 raw = *reinterpret_cast<const f_u32x2*>(row + pxi * S::PXS);
                             acc[f] = BF_MFMA16(wA[gi][a][b], __builtin_bit_cast(f_s16x4, raw), acc[f]);
                         }
@@ -204,21 +216,21 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
     }
 }
 
-template <int CIN, int CMID, int WI>
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
 int front_launch(const stes_block_front_args* a, void* stream) {
-    typedef FrontShape<CIN, CMID, WI> S;
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_front_kernel<CIN, CMID, WI>),
+    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT> S;
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     STES_CHECK(big_lds, STES_ERR_UNSUPPORTED, "stes_block_front_eval: cannot raise the dynamic LDS limit");
     static int resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, block_front_kernel<CIN, CMID, WI>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = per_cu * (cus < 1 ? 256 : cus);
     }
     const int grid = a->N < resident ? a->N : resident;
-    hipLaunchKernelGGL((block_front_kernel<CIN, CMID, WI>), dim3(grid), dim3(256), S::LDS, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>), dim3(grid), dim3(256), S::LDS, (hipStream_t)stream, *a);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -228,10 +240,12 @@ int front_launch(const stes_block_front_args* a, void* stream) {
 extern "C" int stes_block_front_eval(const stes_block_front_args* a, void* stream) {
     STES_CHECK(a && a->X && a->W1 && a->s1 && a->b1 && a->wp2 && a->s2 && a->b2 && a->c2 && a->pooled, STES_ERR_ARG,
                "stes_block_front_eval: null pointer");
-    STES_CHECK(a->N > 0 && a->H > 0 && a->H % 2 == 0, STES_ERR_ARG, "stes_block_front_eval: bad geometry");
+    STES_CHECK(a->N > 0 && a->H > 0 && (a->stride == 1 || (a->stride == 2 && a->H % 2 == 0)), STES_ERR_ARG, "stes_block_front_eval: bad geometry");
     STES_CHECK(a->fold >= 0 && a->fold % 8 == 0 && a->fold <= 32 && a->fold <= a->Cin && (a->fold == 0 || a->G), STES_ERR_ARG,
                "stes_block_front_eval: fold must be a multiple of 8 up to 32 (with G given)");
-    if (a->Cin == 32 && a->Cmid == 64 && a->W == 112) return front_launch<32, 64, 112>(a, stream);
-    if (a->Cin == 64 && a->Cmid == 128 && a->W == 56) return front_launch<64, 128, 56>(a, stream);
-    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_block_front_eval: built for 112 x 112 x 32 -> 64 and 56 x 56 x 64 -> 128 channels");
+    if (a->stride == 2 && a->Cin == 32 && a->Cmid == 64 && a->W == 112) return front_launch<32, 64, 112, 2, 1>(a, stream);
+    if (a->stride == 2 && a->Cin == 64 && a->Cmid == 128 && a->W == 56) return front_launch<64, 128, 56, 2, 1>(a, stream);
+    if (a->stride == 1 && a->Cin == 128 && a->Cmid == 128 && a->W == 28) return front_launch<128, 128, 28, 1, 2>(a, stream);
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_block_front_eval: built for 112 x 112 x 32 -> 64 and 56 x 56 x 64 -> 128 channels with "
+                                                "stride 2 and 28 x 28 x 128 -> 128 channels with stride 1");
 }

@@ -213,12 +213,12 @@ class Block:
         pooled = False
         if (not train and e.block_fused and self.l1.Kp == cin
                 and lib.block_front_takes(cin, cmid, self.Hi, self.Wi, self.stride, k0)):
-            # evaluation, the strided blocks of stages 1 and 2: conv1's output (at the input resolution, the largest tensor of the
-            # network) stays on chip between conv1 and the strided conv2; c2 and the squeeze come out of one kernel
+            # evaluation, the blocks of stages 1 and 2: conv1's output (in the strided blocks, at the input resolution, the largest
+            # tensor of the network) stays on chip between conv1 and conv2; c2 and the squeeze come out of one kernel
             self.bn1.finalize(Mi, train)
             self.bn2.finalize(Mo, train)
             lib.block_front(a_src, a0, k0, self.l1.w_bf, (self.bn1.scale, self.bn1.shift), self.wp2_f, (self.bn2.scale, self.bn2.shift),
-                            self.c2, self.pooled, self.N, self.Hi, self.Wi, cin, cmid)
+                            self.c2, self.pooled, self.N, self.Hi, self.Wi, cin, cmid, self.stride)
             pooled = True
         else:
             lib.gemm(a_src, self.l1.w_bf, self.c1, Mi, cmid, cin, A0=a0, lda0=k0, k0=k0, stats=st(self.bn1))

@@ -66,7 +66,7 @@ BlockFrontArgs = _struct("BlockFrontArgs", [
     ("W1", _P), ("s1", _P), ("b1", _P),
     ("wp2", _P), ("s2", _P), ("b2", _P),
     ("c2", _P), ("pooled", _P),
-    ("N", _I32), ("H", _I32), ("W", _I32), ("Cin", _I32), ("Cmid", _I32)])
+    ("N", _I32), ("H", _I32), ("W", _I32), ("Cin", _I32), ("Cmid", _I32), ("stride", _I32)])
 
 WgradArgs = _struct("WgradArgs", [
     ("P", _P), ("ldp", _I64), ("Q", _P), ("ldq", _I64), ("Q0", _P), ("ldq0", _I64), ("k0", _I32),
@@ -449,23 +449,24 @@ def gemm2(A, W1, H, W2, Cout, M, K1, N1, N2, *, bias1=None, act1=0, relu_mask1=N
 
 
 def block_front_takes(cin, cmid, H, W, stride, fold):
-    """Shapes for which stes_block_front_eval runs conv1 -> bn/act -> strided conv2 (+ squeeze) of a bottleneck in one kernel
-    (the rule in stes_block_front.hip: RegNet-Y 800MF's s1.b1 and s2.b1)."""
-    return stride == 2 and H == W and (cin, cmid, W) in ((32, 64, 112), (64, 128, 56)) and fold % 8 == 0 and fold <= 32
+    """Shapes for which stes_block_front_eval runs conv1 -> bn/act -> conv2 (+ squeeze) of a bottleneck in one kernel (the rule
+    in stes_block_front.hip: RegNet-Y 800MF's s1.b1, s2.b1 and the identity blocks of stage 2)."""
+    return H == W and (stride, cin, cmid, W) in ((2, 32, 64, 112), (2, 64, 128, 56), (1, 128, 128, 28)) and fold % 8 == 0 and fold <= 32
 
 
-def block_front(X, G, fold, W1, bn1, wp2, bn2, c2, pooled, N, H, W, cin, cmid):
-    """conv1 + bn1/ReLU + strided grouped conv2 + squeeze of a strided bottleneck in evaluation mode; see stes_block_front_eval."""
+def block_front(X, G, fold, W1, bn1, wp2, bn2, c2, pooled, N, H, W, cin, cmid, stride):
+    """conv1 + bn1/ReLU + grouped conv2 + squeeze of a bottleneck in evaluation mode; see stes_block_front_eval."""
     a = BlockFrontArgs()
     a.X, a.G, a.fold = ptr(X), ptr(G), fold
     a.W1, a.s1, a.b1 = ptr(W1), ptr(bn1[0]), ptr(bn1[1])
     a.wp2, a.s2, a.b2 = ptr(wp2), ptr(bn2[0]), ptr(bn2[1])
     a.c2, a.pooled = ptr(c2), ptr(pooled)
-    a.N, a.H, a.W, a.Cin, a.Cmid = N, H, W, cin, cmid
+    a.N, a.H, a.W, a.Cin, a.Cmid, a.stride = N, H, W, cin, cmid, stride
     fn = lambda: check(lib().stes_block_front_eval(C.byref(a), stream()), "stes_block_front_eval")
     if TIMING is not None:
         m = N * H * W
-        _timed("block_front_kernel<%d, %d, %d>" % (cin, cmid, W), 2 * m * cin + 2 * (m // 4) * cmid, 2 * m * cin * cmid + 2 * (m // 4) * cmid * 144, fn)
+        mo = m // (stride * stride)
+        _timed("block_front_kernel<%d, %d, %d, %d>" % (cin, cmid, W, stride), 2 * m * cin + 2 * mo * cmid, 2 * m * cin * cmid + 2 * mo * cmid * 144, fn)
         return
     fn()
 

@@ -257,21 +257,22 @@ def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
         assert torch.equal(Y.view(torch.int16), ref.view(torch.int16)), backward
 
 
-@pytest.mark.parametrize("N,cin,cmid,Wd,fold", [(5, 32, 64, 112, 8), (9, 64, 128, 56, 16), (600, 64, 128, 56, 16), (3, 32, 64, 112, 0)])
-def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold):
-    """conv1 -> bn1/ReLU -> strided grouped conv2 (+ squeeze) of a strided bottleneck in one kernel against stes_gemm followed by
+@pytest.mark.parametrize("N,cin,cmid,Wd,fold,stride", [(5, 32, 64, 112, 8, 2), (9, 64, 128, 56, 16, 2), (600, 64, 128, 56, 16, 2), (3, 32, 64, 112, 0, 2),
+                                                        (11, 128, 128, 28, 32, 1), (900, 128, 128, 28, 32, 1), (2, 128, 128, 28, 0, 1)])
+def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold, stride):
+    """conv1 -> bn1/ReLU -> grouped conv2 (+ squeeze) of a bottleneck in one kernel against stes_gemm followed by
     stes_conv3x3g_fwd_pool: same roundings, so c2 agrees to fp32 summation order (an odd bf16 ulp) and the squeeze to its bf16
     rounding."""
     from spot_amd import lib
     g = torch.Generator().manual_seed(7 * N + cin)
     M = N * Wd * Wd
-    Mo = M // 4
+    Mo = M // (stride * stride)
     X = dev(bfr(M, cin, g=g).abs())
     G = dev(bfr(M, fold, g=g).abs()) if fold else None
     W1 = dev((torch.randn(cmid, cin, generator=g) / cin ** 0.5).to(BF))
     w2 = dev(torch.randn(cmid, 16, 3, 3, generator=g) / 12.0)
     wpf = torch.empty(cmid // 16 * 5 * 512, dtype=BF, device="cuda"); wpd = torch.empty_like(wpf)
-    lib.call("stes_pack_conv3x3g", lib.ptr(w2), lib.ptr(wpf), lib.ptr(wpd), cmid // 16, 2)
+    lib.call("stes_pack_conv3x3g", lib.ptr(w2), lib.ptr(wpf), lib.ptr(wpd), cmid // 16, stride)
     bns = [(dev(torch.rand(cmid, generator=g) + 0.5), dev(torch.randn(cmid, generator=g) * 0.2)) for _ in range(2)]
     c1 = torch.empty(M, cmid, dtype=BF, device="cuda")
     ref = torch.empty(Mo, cmid, dtype=BF, device="cuda"); ref_pool = torch.empty(N, cmid, dtype=BF, device="cuda")
@@ -280,9 +281,9 @@ def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold):
     else:
         lib.gemm(X, W1, c1, M, cmid, cin)
     lib.call("stes_conv3x3g_fwd_pool", lib.ptr(c1), lib.ptr(wpf), lib.ptr(ref), lib.ptr(bns[0][0]), lib.ptr(bns[0][1]), lib.ptr(bns[1][0]),
-             lib.ptr(bns[1][1]), lib.ptr(ref_pool), N, Wd, Wd, Wd // 2, Wd // 2, 2, cmid)
+             lib.ptr(bns[1][1]), lib.ptr(ref_pool), N, Wd, Wd, Wd // stride, Wd // stride, stride, cmid)
     out = torch.full((Mo, cmid), 9.0, dtype=BF, device="cuda"); pool = torch.full((N, cmid), 9.0, dtype=BF, device="cuda")
-    lib.block_front(X, G, fold, W1, bns[0], wpf, bns[1], out, pool, N, Wd, Wd, cin, cmid)
+    lib.block_front(X, G, fold, W1, bns[0], wpf, bns[1], out, pool, N, Wd, Wd, cin, cmid, stride)
     torch.cuda.synchronize()
     a, b = out.float().cpu(), ref.float().cpu()
     assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())

@@ -66,7 +66,7 @@ def test_eval_forward_vs_reference_golden(golden):
 
 def test_eval_forward_224_fused_stage3_blocks_match_the_kernel_sequence():
     """At 224 x 224 the seven identity bottlenecks of stage 3 (14 x 14 x 320) run as one kernel each in evaluation mode
-    (stes_block_eval_s3), and conv1 + strided conv2 of the first blocks of stages 1 and 2 as one kernel each (stes_block_front_eval).  Same model, same clip, with that path on and off: the features agree to bf16 rounding noise
+    (stes_block_eval_s3), and conv1 + conv2 of the blocks of stages 1 and 2 as one kernel each (stes_block_front_eval).  Same model, same clip, with that path on and off: the features agree to bf16 rounding noise
     (both paths round at the same points; fp32 summation order differs), far inside the 1e-2 stated against fp32."""
     from spot_amd import lib
     om, m = build(clip_len=4)
@@ -85,7 +85,7 @@ def test_eval_forward_224_fused_stage3_blocks_match_the_kernel_sequence():
             fronts = sum(1 for rec in lib.TIMING if rec[0].startswith("block_front"))
         finally:
             lib.TIMING = None
-        assert launches == (7 if fused else 0) and fronts == (2 if fused else 0), (launches, fronts)
+        assert launches == (7 if fused else 0) and fronts == (4 if fused else 0), (launches, fronts)
         out[fused] = {k: d[k].float().cpu() for k in ("cnn_feat", "im_feat", "loc_feat")}
     eng.block_fused = True
     for k in out[True]:
