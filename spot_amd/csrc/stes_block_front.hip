@@ -81,6 +81,21 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) wA[gi][a][b] = bf_tap_frag((const bf16*)p.wp2, wave + 4 * gi, a * 3 + b, lane);
+    // bn1's affine map for the channels this lane holds after conv1 (in registers where the wave's share is at most 64 channels)
+    constexpr bool BN1_REGS = S::NTW <= 4;
+    float sc1[BN1_REGS ? S::NTW : 1][4], sh1[BN1_REGS ? S::NTW : 1][4];
+    if (BN1_REGS) {
+#pragma unroll
+        for (int j = 0; j < S::NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc1[j][e] = p.s1[16 * (nt0 + j) + 4 * fq + e]; sh1[j][e] = p.b1[16 * (nt0 + j) + 4 * fq + e]; }
+    }
+    // bn2's affine map for the channels this lane holds after conv2
+    float sc2[S::GPW][4], sh2[S::GPW][4];
+#pragma unroll
+    for (int gi = 0; gi < S::GPW; ++gi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc2[gi][e] = p.s2[(wave + 4 * gi) * 16 + 4 * fq + e]; sh2[gi][e] = p.b2[(wave + 4 * gi) * 16 + 4 * fq + e]; }
     __syncthreads();
 
     for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
@@ -151,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int ch = 16 * (nt0 + j) + 4 * fq + e;
-                            o[e] = inside ? (bf16)fmaxf((float)(bf16)acc[j][e] * s1[ch] + b1[ch], 0.f) : (bf16)0.f;
+                            const float sc = BN1_REGS ? sc1[BN1_REGS ? j : 0][e] : s1[ch], sh = BN1_REGS ? sh1[BN1_REGS ? j : 0][e] : b1[ch];
+                            o[e] = inside ? (bf16)fmaxf((float)(bf16)acc[j][e] * sc + sh, 0.f) : (bf16)0.f;
                         }
                         *reinterpret_cast<bf16x4*>(dstp + 16 * j) = o;
                     }
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
                         for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[f][e];
                         *reinterpret_cast<bf16x4*>(stage + co * S::SPX + ch0) = ob;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) psum[gi][e] += fmaxf((float)ob[e] * s2[ch0 + e] + b2[ch0 + e], 0.f);
+                        for (int e = 0; e < 4; ++e) psum[gi][e] += fmaxf((float)ob[e] * sc2[gi][e] + sh2[gi][e], 0.f);
                     }
                 }
             }
