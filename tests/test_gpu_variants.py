@@ -303,6 +303,23 @@ def test_uint8_frames_equal_the_loaders_normalised_tensor():
     assert rel(lb[:3], la[:3]) < 2e-2, (la, lb)
 
 
+def test_predict_async_returns_what_predict_returns_and_keeps_its_results():
+    """predict_async (no read-back, used by the sliding-window loop to enqueue a batch before it reads the previous one): the
+    same scores and locations as predict(), in tensors that a later forward does not overwrite."""
+    om, m = _pair("rny008_gsm", "gru", clip_len=8, seed=3)
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(2, 8, 3, 64, 64, generator=g)
+    b = torch.randn(2, 8, 3, 64, 64, generator=g)
+    _, scores_a, loc_a = m.predict(a)
+    sa, la = m.predict_async(a)
+    sb, lb = m.predict_async(b)              # a second forward while the first results are still on the device
+    torch.cuda.synchronize()
+    assert np.array_equal(sa.cpu().numpy(), scores_a) and np.array_equal(la.cpu().numpy(), loc_a)
+    _, scores_b, loc_b = m.predict(b)
+    assert np.array_equal(sb.cpu().numpy(), scores_b) and np.array_equal(lb.cpu().numpy(), loc_b)
+    assert np.array_equal(sa.cpu().numpy(), scores_a)          # still the first batch's
+
+
 def test_sliding_window_events_match_oracle():
     """Long-video path: windows of clip_len frames, last one zero-padded, per-frame scores -> argmax events ->
     score filter 0.15 -> NMS(3).  Event frames and labels must be identical to the CPU oracle's on the same clip."""
