@@ -270,6 +270,14 @@ int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int
                        int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
                        int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
                        float* s_dyr2, const uint8_t* x_bits, void* stream);
+/* The same with the adjoint of the plain temporal shift (TemporalShift, reference model/shift.py:37-52) applied to dY while it is
+ * read: channels [0, tsm_fold) take frame t-1's gradient, [tsm_fold, 2 tsm_fold) frame t+1's, zero beyond a clip of T frames
+ * (rows = clips x T x Hi x Wi).  Replaces stes_tsm_shift(..., backward = 1) in front of stes_block_in_grad.  tsm_fold % 4 == 0,
+ * fold == 0. */
+int stes_block_in_grad_tsm(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
+                           int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
+                           int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
+                           float* s_dyr2, const uint8_t* x_bits, int tsm_fold, int T, void* stream);
 /* Backward of global average pooling + the last block's ReLU: dZ = (da+db)/HW * (out>0). */
 int stes_pool_bwd(const float* da, const float* db, const uint16_t* out, uint16_t* dZ, int N, int HW, int C, void* stream);
 

@@ -452,7 +452,8 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
                                                             long M, int C, FastDiv fd_hw, FastDiv fd_wi,
                                                             const bf16* __restrict__ raw1, const bf16* __restrict__ raw2,
                                                             float* __restrict__ s_dy, float* __restrict__ s_dyr1,
-                                                            float* __restrict__ s_dyr2, const uint8_t* __restrict__ x_bits, StesDet det) {
+                                                            float* __restrict__ s_dyr2, const uint8_t* __restrict__ x_bits, StesDet det,
+                                                            int tsm_fold, FastDiv fd_T) {
     extern __shared__ float lds[];     // [3][C] when SUMS
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -478,7 +479,29 @@ __global__ __launch_bounds__(TPB) void block_in_grad_kernel(const bf16* __restri
             live[u] = m < M;
             rok[u] = false;
             if (!live[u]) continue;
-            rv[u] = (c0 < fold) ? *reinterpret_cast<const bf16x8*>(dXf + m * fold + c0) : *reinterpret_cast<const bf16x8*>(dY + m * ldy + c0);
+            if (c0 < 2 * tsm_fold) {
+                // the adjoint of the plain temporal shift (reference model/shift.py:37-52), taken while dY is read: channels
+                // [0, fold) get the gradient of frame t-1, [fold, 2 fold) that of frame t+1, zero beyond the clip; four channels
+                // at a time (fold is a multiple of 4, so a piece lies in one segment)
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                uint32_t nimg, rem, clip, t;
+                fdivmod((uint32_t)m, fd_hw, nimg, rem);
+                fdivmod(nimg, fd_T, clip, t);
+                const long plane = (long)Hi * Wi;
+                u32x2 half[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = c0 + 4 * h;
+                    const int step = c < tsm_fold ? -1 : (c < 2 * tsm_fold ? 1 : 0);
+                    const int ts = (int)t + step;
+                    half[h] = (u32x2){0u, 0u};
+                    if (ts >= 0 && ts < (int)fd_T.d) half[h] = *reinterpret_cast<const u32x2*>(dY + (m + step * plane) * ldy + c);
+                }
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                rv[u] = __builtin_bit_cast(bf16x8, (u32x4){half[0][0], half[0][1], half[1][0], half[1][1]});
+            } else {
+                rv[u] = (c0 < fold) ? *reinterpret_cast<const bf16x8*>(dXf + m * fold + c0) : *reinterpret_cast<const bf16x8*>(dY + m * ldy + c0);
+            }
             if (resid) {
                 long rm = m; bool ok = true;
                 if (ms > 1) {
@@ -763,7 +786,17 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
                                   int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
                                   int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
                                   float* s_dyr2, const uint8_t* x_bits, void* stream) {
+    return stes_block_in_grad_tsm(dY, ldy, dXf, fold, resid, map_stride, Ho, Wo, Hi, Wi, X, out, M, C, raw1, raw2, s_dy, s_dyr1, s_dyr2,
+                                  x_bits, 0, 1, stream);
+}
+
+extern "C" int stes_block_in_grad_tsm(const uint16_t* dY, int64_t ldy, const uint16_t* dXf, int fold, const uint16_t* resid,
+                                      int map_stride, int Ho, int Wo, int Hi, int Wi, const uint16_t* X, uint16_t* out,
+                                      int64_t M, int C, const uint16_t* raw1, const uint16_t* raw2, float* s_dy, float* s_dyr1,
+                                      float* s_dyr2, const uint8_t* x_bits, int tsm_fold, int T, void* stream) {
     STES_CHECK(dY && (X || x_bits) && out && M > 0, STES_ERR_ARG, "stes_block_in_grad: null pointer");
+    STES_CHECK(tsm_fold >= 0 && tsm_fold % 4 == 0 && 2 * tsm_fold <= C && T > 0 && (tsm_fold == 0 || (fold == 0 && M % ((int64_t)Hi * Wi * T) == 0)),
+               STES_ERR_ARG, "stes_block_in_grad_tsm: the shifted width must be a multiple of 4, without a gated-shift slice, on whole clips");
     STES_CHECK(C % 8 == 0 && fold % 8 == 0 && ldy % 8 == 0 && (fold == 0 || dXf), STES_ERR_ARG, "stes_block_in_grad: alignment");
     STES_CHECK(map_stride == 1 || map_stride == 2, STES_ERR_UNSUPPORTED, "stes_block_in_grad: stride must be 1 or 2");
     STES_CHECK(M <= 0xffffffffL, STES_ERR_UNSUPPORTED, "stes_block_in_grad: tensor too large");
@@ -776,11 +809,12 @@ extern "C" int stes_block_in_grad(const uint16_t* dY, int64_t ldy, const uint16_
     if (raw1)
         hipLaunchKernelGGL(block_in_grad_kernel<true>, dim3(grid), dim3(TPB), 3 * C * sizeof(float), S(stream), (const bf16*)dY, (long)ldy,
                            (const bf16*)dXf, fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C,
-                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2, x_bits, stes_det_take(grid));
+                           fhw, fwi, (const bf16*)raw1, (const bf16*)raw2, s_dy, s_dyr1, s_dyr2, x_bits, stes_det_take(grid), tsm_fold, make_fastdiv(T));
     else
         hipLaunchKernelGGL(block_in_grad_kernel<false>, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)dY, (long)ldy, (const bf16*)dXf,
                            fold, (const bf16*)resid, map_stride, Ho, Wo, Hi, Wi, (const bf16*)X, (bf16*)out, (long)M, C, fhw, fwi,
-                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, x_bits, StesDet{nullptr, 0u, 0u});
+                           (const bf16*)nullptr, (const bf16*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, x_bits, StesDet{nullptr, 0u, 0u},
+                           tsm_fold, make_fastdiv(T));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

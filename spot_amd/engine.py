@@ -380,7 +380,7 @@ class Block:
             lib.call("stes_gsm_bwd_dx", p(dG), p(Xc), p(self.gate), p(dxbn), p(bng.alpha), p(bng.beta), p(bng.delta), p(dXf), C.byref(geom))
         elif self.kind == "tsm":
             if self.tsm_inplace:
-                lib.call("stes_tsm_shift_inplace", p(dY1), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
+                pass            # the adjoint shift is taken by stes_block_in_grad_tsm below while it reads dY1
             else:
                 dY1s = sc("tsm.dY1s", Mi * cin)
                 lib.call("stes_tsm_shift", p(dY1), p(dY1s), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 1)
@@ -412,8 +412,12 @@ class Block:
             front = (prev.c3, prev.sc if prev.down else None, prev.bn3.s_dy, prev.bn3.s_dyr, prev.bnd.s_dyr if prev.down else None)
         else:
             front = (e.c0, None, e.bn0.s_dy, e.bn0.s_dyr, None)
-        lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
-                 p(dZp), Mi, cin, *[p(t) for t in front], p(self.xbits))
+        if self.kind == "tsm" and self.tsm_inplace:
+            lib.call("stes_block_in_grad_tsm", p(dY1), cin, None, 0, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
+                     p(dZp), Mi, cin, *[p(t) for t in front], p(self.xbits), self.tsm_fold, self.T)
+        else:
+            lib.call("stes_block_in_grad", p(dY1), cin, p(dXf), self.fold, p(resid), ms, self.Ho, self.Wo, self.Hi, self.Wi, p(a_src),
+                     p(dZp), Mi, cin, *[p(t) for t in front], p(self.xbits))
         e.side_done[par] = e.side.record_event()
         return dZp
 

@@ -117,6 +117,7 @@ _SIGS = {
     "stes_bn_bwd_finalize": [_P, _P, _P, _P, _P, _F64, _P, _P, _P, _P, _P, _I32, _P],
     "stes_bn_bwd_apply": [_P, _P],
     "stes_block_in_grad": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "stes_block_in_grad_tsm": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "stes_pool_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_pack_conv3x3g": [_P, _P, _P, _I32, _I32, _P],
     "stes_conv3x3g_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
@@ -303,6 +304,7 @@ _KERNEL_OF = {
                            + (a[12] * a[13] // 8 if a[19] is not None else 2 * a[12] * a[13])
                            + (2 * a[12] * a[13] // (a[5] * a[5]) if a[4] is not None else 0)),
 }
+_KERNEL_OF["stes_block_in_grad_tsm"] = _KERNEL_OF["stes_block_in_grad"]          # (same kernel, same bytes)
 
 
 def _timed(kernel, nbytes, flops, fn):

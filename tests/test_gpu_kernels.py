@@ -241,6 +241,34 @@ def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
         lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
 
 
+@pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 4, 6, 32, 4), (1, 8, 2, 2, 64, 8), (2, 7, 3, 3, 320, 40)])
+def test_block_in_grad_takes_the_adjoint_temporal_shift_on_its_way(B, T, H, W, Cc, fold):
+    """stes_block_in_grad_tsm against stes_tsm_shift(backward) followed by stes_block_in_grad, bit for bit (output and the
+    BatchNorm-backward sums' inputs are the same values in the same order)."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(B + T + Cc)
+    M = B * T * H * W
+    dY, X, raw = dev(bfr(M, Cc, g=g)), dev(bfr(M, Cc, g=g)), dev(bfr(M, Cc, g=g))
+    outs = []
+    for fused in (False, True):
+        out = torch.empty(M, Cc, dtype=BF, device="cuda")
+        sums = [torch.zeros(Cc, device="cuda") for _ in range(2)]
+        if fused:
+            lib.call("stes_block_in_grad_tsm", lib.ptr(dY), Cc, None, 0, lib.ptr(dY), 1, H, W, H, W, lib.ptr(X), lib.ptr(out), M, Cc,
+                     lib.ptr(raw), None, lib.ptr(sums[0]), lib.ptr(sums[1]), None, None, fold, T)
+        else:
+            sh = torch.empty_like(dY)
+            lib.call("stes_tsm_shift", lib.ptr(dY), lib.ptr(sh), fold, Cc, B, T, H, W, 1)
+            # (the residual is the unshifted tensor in both forms)
+            lib.call("stes_block_in_grad", lib.ptr(sh), Cc, None, 0, lib.ptr(dY), 1, H, W, H, W, lib.ptr(X), lib.ptr(out), M, Cc,
+                     lib.ptr(raw), None, lib.ptr(sums[0]), lib.ptr(sums[1]), None, None)
+        torch.cuda.synchronize()
+        outs.append((out, sums))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    for a, b in zip(outs[0][1], outs[1][1]):
+        close(a.cpu(), b.cpu(), 1e-5, 1e-4)
+
+
 @pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 3, 4, 32, 4), (1, 8, 2, 2, 64, 8), (3, 19, 1, 5, 320, 40), (1, 1, 2, 3, 32, 4), (2, 64, 7, 7, 768, 96)])
 def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
     """The temporal shift (reference model/shift.py:37-52) applied in place -- only the moving channels are touched, frames walked
