@@ -201,6 +201,12 @@ int stes_bn_act_residual(const uint16_t* c, const float* scale, const float* shi
                          const float* res_scale, const float* res_shift, uint16_t* out, float* stat_sum,
                          float* stat_sumsq, int stat_c, uint16_t* slice_out, int64_t M, int C, uint8_t* relu_bits,
                          void* stream);
+/* The same for a block whose successor applies the plain temporal shift (TemporalShift, reference model/shift.py:37-66, which
+ * shifts its input in place): the shift is taken in the store, so out is the shifted tensor and no shift pass follows.
+ * Rows = clips x T frames x HW pixels; tsm_fold % 4 == 0. */
+int stes_bn_act_residual_tsm(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
+                             const float* res_scale, const float* res_shift, uint16_t* out, int64_t M, int C,
+                             int tsm_fold, int T, int HW, void* stream);
 
 /* out[n,ch] = norm * sum_hw act(c[n,hw,ch]) * (mul ? mul[n,hw,ch] : 1), act = relu(scale*c+shift)
  * when scale is given.  Squeeze of timm SEModule, its backward, and the head's global pool.   */

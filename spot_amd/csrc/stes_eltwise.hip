@@ -67,7 +67,7 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
     const bf16* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
     bf16* __restrict__ out, float* stat_sum, float* stat_sumsq, int stat_c, bf16* __restrict__ slice_out, long M, int C,
-    uint8_t* __restrict__ relu_bits, StesDet det) {
+    uint8_t* __restrict__ relu_bits, StesDet det, int tsm_fold, FastDiv fd_hw, FastDiv fd_T) {
     extern __shared__ float lds[];     // [2][stat_c]
     const int CH = C / 8;
     const long gt = (long)blockIdx.x * TPB + threadIdx.x;
@@ -100,7 +100,31 @@ __global__ __launch_bounds__(TPB) void bn_act_residual_kernel(
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { o[i] = (bf16)fmaxf(v[i], 0.f); v[i] = (float)o[i]; }
-        *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+        if (c0 < 2 * tsm_fold) {
+            // the next block's plain temporal shift (reference model/shift.py:37-52) taken in the store: channels [0, fold) of
+            // frame t belong in frame t-1, [fold, 2 fold) in frame t+1; the value that would leave the clip is dropped and its
+            // writer puts the zero into the frame at the other end that gets no value (four channels at a time)
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 raw = __builtin_bit_cast(u32x4, o);
+            uint32_t nimg, rem, clip, t;
+            fdivmod((uint32_t)m, fd_hw, nimg, rem);
+            fdivmod(nimg, fd_T, clip, t);
+            const long plane = fd_hw.d;
+            const int T = (int)fd_T.d;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = c0 + 4 * h;
+                const int step = cc < tsm_fold ? -1 : (cc < 2 * tsm_fold ? 1 : 0);          // destination frame = t + step
+                const int td = (int)t + step;
+                const bool inside = td >= 0 && td < T;
+                const long md = inside ? m + step * plane : m - (long)step * (T - 1) * plane;
+                const u32x2 val = inside ? (u32x2){raw[2 * h], raw[2 * h + 1]} : (u32x2){0u, 0u};
+                *reinterpret_cast<u32x2*>(out + md * C + cc) = val;
+            }
+        } else {
+            *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+        }
         if (relu_bits) {                           // bit i: out[m, c0 + i] > 0 (what the block input gradient masks with)
             unsigned bits = 0;
 #pragma unroll
@@ -627,7 +651,23 @@ extern "C" int stes_bn_act_residual(const uint16_t* c, const float* scale, const
     const int grid = flat_grid(M, C / 8, cap < 1024 ? cap : 1024);
     hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 2 * stat_c * sizeof(float), S(stream), (const bf16*)c, scale,
                        shift, (const bf16*)res, res_scale, res_shift, (bf16*)out, stat_sum, stat_sumsq, stat_c, (bf16*)slice_out, (long)M, C, relu_bits,
-                       stat_c > 0 && stat_sum ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u});
+                       stat_c > 0 && stat_sum ? stes_det_take(grid) : StesDet{nullptr, 0u, 0u}, 0, make_fastdiv(1), make_fastdiv(1));
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+extern "C" int stes_bn_act_residual_tsm(const uint16_t* c, const float* scale, const float* shift, const uint16_t* res,
+                                        const float* res_scale, const float* res_shift, uint16_t* out, int64_t M, int C,
+                                        int tsm_fold, int T, int HW, void* stream) {
+    STES_CHECK(c && scale && shift && out && M > 0, STES_ERR_ARG, "stes_bn_act_residual_tsm: null pointer");
+    STES_CHECK(C % 8 == 0 && (res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), STES_ERR_ARG, "stes_bn_act_residual_tsm: bad argument");
+    STES_CHECK(tsm_fold >= 0 && tsm_fold % 4 == 0 && 2 * tsm_fold <= C && T > 0 && HW > 0 && M % ((int64_t)T * HW) == 0 && M <= 0xffffffffL,
+               STES_ERR_ARG, "stes_bn_act_residual_tsm: the shifted width must be a multiple of 4, on whole clips");
+    static const int cap = resident_blocks(bn_act_residual_kernel);
+    const int grid = flat_grid(M, C / 8, cap < 1024 ? cap : 1024);
+    hipLaunchKernelGGL(bn_act_residual_kernel, dim3(grid), dim3(TPB), 0, S(stream), (const bf16*)c, scale, shift, (const bf16*)res, res_scale,
+                       res_shift, (bf16*)out, (float*)nullptr, (float*)nullptr, 0, (bf16*)nullptr, (long)M, C, (uint8_t*)nullptr,
+                       StesDet{nullptr, 0u, 0u}, tsm_fold, make_fastdiv(HW), make_fastdiv(T));
     STES_LAUNCH_CHECK();
     return STES_OK;
 }

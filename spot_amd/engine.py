@@ -93,6 +93,7 @@ class Block:
         self.eng, self.name = eng, name
         c1 = blk.conv1
         self.kind = "gsm" if isinstance(c1, GatedShift) else ("tsm" if isinstance(c1, TemporalShift) else "none")
+        self.pre_shifted = False
         conv1 = c1.net if self.kind != "none" else c1
         self.cin, self.cmid, self.stride = conv1.conv.in_channels, conv1.conv.out_channels, blk.conv2.conv.stride[0]
         self.cout = blk.conv3.conv.out_channels
@@ -190,7 +191,9 @@ class Block:
             a0, k0 = self.G, self.fold
         elif self.kind == "tsm":
             if self.tsm_inplace:
-                lib.call("stes_tsm_shift_inplace", p(X), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
+                if not self.pre_shifted:           # (in training the kernel that wrote X has shifted it on its way out)
+                    lib.call("stes_tsm_shift_inplace", p(X), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
+                self.pre_shifted = False
             else:
                 lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
                 a_src = self.Xs
@@ -553,6 +556,12 @@ class Engine:
             fold, slc = nxt.fold, nxt.Xc
             if train:
                 ssum, ssq = nxt.bng.sum, nxt.bng.sumsq
+        if nxt is not None and nxt.kind == "tsm" and nxt.tsm_inplace and train:
+            # the next block's temporal shift is taken in this kernel's store: `out` is the shifted tensor
+            lib.call("stes_bn_act_residual_tsm", p(c), p(bn.scale), p(bn.shift), p(res), p(rs), p(rb), p(out), M, Cc, nxt.tsm_fold,
+                     self.T, M // self.N)
+            nxt.pre_shifted = True
+            return
         bits = nxt.xbits if nxt is not None and train else None
         lib.call("stes_bn_act_residual", p(c), p(bn.scale), p(bn.shift), p(res), p(rs), p(rb), p(out), p(ssum), p(ssq), fold, p(slc), M, Cc,
                  p(bits))

@@ -106,6 +106,7 @@ _SIGS = {
     "stes_block_front_eval": [_P, _P],
     "stes_bn_finalize": [_P, _P, _F64, _P, _P, _P, _P, _F32, _F32, _I32, _P, _P, _P, _P, _I32, _P],
     "stes_bn_act_residual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P],
+    "stes_bn_act_residual_tsm": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "stes_chan_pool": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
     "stes_bn_act_gate": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stes_sigmoid_bwd": [_P, _P, _P, _I64, _P],
@@ -305,6 +306,7 @@ _KERNEL_OF = {
                            + (2 * a[12] * a[13] // (a[5] * a[5]) if a[4] is not None else 0)),
 }
 _KERNEL_OF["stes_block_in_grad_tsm"] = _KERNEL_OF["stes_block_in_grad"]          # (same kernel, same bytes)
+_KERNEL_OF["stes_bn_act_residual_tsm"] = ("bn_act_residual_kernel", lambda a: 2 * a[7] * a[8] * (2 + (a[3] is not None)))
 
 
 def _timed(kernel, nbytes, flops, fn):

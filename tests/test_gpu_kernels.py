@@ -241,6 +241,23 @@ def test_stem_conv_one_pass_equals_patches_then_gemm(B, T, Tv, H, W, u8):
         lib.call("stes_stem_conv", *args, None, lib.ptr(got), None, None, None, None, None, 0, B, T, Tv, 3, H, W)
 
 
+@pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 4, 6, 32, 4), (1, 8, 2, 2, 64, 8), (2, 7, 3, 3, 320, 40), (3, 1, 2, 2, 32, 4)])
+def test_block_tail_takes_the_next_blocks_temporal_shift_in_its_store(B, T, H, W, Cc, fold):
+    """stes_bn_act_residual_tsm against stes_bn_act_residual followed by the temporal shift, bit for bit."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(B + T + Cc)
+    M = B * T * H * W
+    c, res = dev(bfr(M, Cc, g=g)), dev(bfr(M, Cc, g=g))
+    sc, sh = dev(torch.rand(Cc, generator=g) + 0.5), dev(torch.randn(Cc, generator=g) * 0.3)
+    plain = torch.empty(M, Cc, dtype=BF, device="cuda"); ref = torch.empty_like(plain)
+    lib.call("stes_bn_act_residual", lib.ptr(c), lib.ptr(sc), lib.ptr(sh), lib.ptr(res), None, None, lib.ptr(plain), None, None, 0, None, M, Cc, None)
+    lib.call("stes_tsm_shift", lib.ptr(plain), lib.ptr(ref), fold, Cc, B, T, H, W, 0)
+    out = torch.full((M, Cc), 7.0, dtype=BF, device="cuda")
+    lib.call("stes_bn_act_residual_tsm", lib.ptr(c), lib.ptr(sc), lib.ptr(sh), lib.ptr(res), None, None, lib.ptr(out), M, Cc, fold, T, H * W)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 4, 6, 32, 4), (1, 8, 2, 2, 64, 8), (2, 7, 3, 3, 320, 40)])
 def test_block_in_grad_takes_the_adjoint_temporal_shift_on_its_way(B, T, H, W, Cc, fold):
     """stes_block_in_grad_tsm against stes_tsm_shift(backward) followed by stes_block_in_grad, bit for bit (output and the
