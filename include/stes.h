@@ -120,7 +120,7 @@ int stes_block_front_eval(const stes_block_front_args* a, void* stream);
  * shift's result G for the first `fold` channels of conv1's input.  BatchNorms are the evaluation-mode affine maps
  * (scale, shift as stes_bn_finalize gives them with training == 0).  Same roundings as the kernel sequence
  * stes_gemm / stes_conv3x3g_fwd_pool / stes_gemm_small2 / stes_gemm with the block-tail epilogue.
- * X: block input [N*H*W][C]; G: [N*H*W][fold]; W1, W3: [C][C] bf16 (W1 with the fold-permuted columns stes_gemm takes);
+ * X: block input [N*H*W][C]; G: [N*H*W][fold] (fold = 80, or 0 and G = NULL for a block without a gated shift); W1, W3: [C][C] bf16 (W1 with the fold-permuted columns stes_gemm takes);
  * wp2: stes_pack_conv3x3g's forward pack; Wse1 [rd][C], Wse2 [C][rd] bf16 with fp32 biases; out: [N*H*W][C];
  * slice (optional): the first slice_n channels of out as [N*H*W][slice_n] (the next block's gated-shift slice). */
 typedef struct {

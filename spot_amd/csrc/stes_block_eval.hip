@@ -211,6 +211,7 @@ __global__ __launch_bounds__(BE_THREADS) void block_eval_s3_kernel(const stes_bl
     }
     const bf16* __restrict__ X = (const bf16*)p.X;
     const bf16* __restrict__ G = (const bf16*)p.G;
+    const int fold = p.fold;                          // 80 with a gated shift in front of conv1, 0 without
     static_assert(BE_THREADS * BE_BATCH >= BE_CHUNKS, "a thread's chunks of an image are one batch");
     // the first image's input rows (the first 80 channels from G, the rest from X) go to LDS in whole 16-byte chunks; the later
     // images' arrive in the pass that writes the image before them out
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(BE_THREADS) void block_eval_s3_kernel(const stes_bl
         for (int u = 0; u < BE_BATCH; ++u) {
             const int idx = min(u * BE_THREADS + tv, BE_CHUNKS - 1);         // (the clamped tail moves the last chunk again)
             const int m = idx / (BE_C / 8), c0 = (idx - m * (BE_C / 8)) * 8;
-            const bf16* src = c0 < BE_FOLD ? G + (row0 + m) * BE_FOLD + c0 : X + (row0 + m) * BE_C + c0;
+            const bf16* src = c0 < fold ? G + (row0 + m) * fold + c0 : X + (row0 + m) * BE_C + c0;
             v[u] = *reinterpret_cast<const bf16x8*>(src);
         }
 #pragma unroll
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(BE_THREADS) void block_eval_s3_kernel(const stes_bl
                 for (int u = 0; u < BE_BATCH; ++u) {
                     const int idx = min(u * BE_THREADS + tv, BE_CHUNKS - 1);
                     const int m = idx / (BE_C / 8), c0 = (idx - m * (BE_C / 8)) * 8;
-                    const bf16* src = c0 < BE_FOLD ? G + (row0n + m) * BE_FOLD + c0 : X + (row0n + m) * BE_C + c0;
+                    const bf16* src = c0 < fold ? G + (row0n + m) * fold + c0 : X + (row0n + m) * BE_C + c0;
                     nx[u] = *reinterpret_cast<const bf16x8*>(src);
                 }
             }
@@ -364,11 +365,11 @@ __global__ __launch_bounds__(BE_THREADS) void block_eval_s3_kernel(const stes_bl
 }  // namespace
 
 extern "C" int stes_block_eval_s3(const stes_block_eval_args* a, void* stream) {
-    STES_CHECK(a && a->X && a->G && a->W1 && a->wp2 && a->Wse1 && a->Wse2 && a->W3 && a->out, STES_ERR_ARG, "stes_block_eval_s3: null pointer");
+    STES_CHECK(a && a->X && (a->G || a->fold == 0) && a->W1 && a->wp2 && a->Wse1 && a->Wse2 && a->W3 && a->out, STES_ERR_ARG, "stes_block_eval_s3: null pointer");
     STES_CHECK(a->s1 && a->b1 && a->s2 && a->b2 && a->s3 && a->b3 && a->bse1 && a->bse2, STES_ERR_ARG, "stes_block_eval_s3: null pointer");
     STES_CHECK(a->N > 0, STES_ERR_ARG, "stes_block_eval_s3: no images");
-    STES_CHECK(a->C == BE_C && a->H == BE_W && a->W == BE_W && a->rd == BE_RD && a->fold == BE_FOLD, STES_ERR_UNSUPPORTED,
-               "stes_block_eval_s3: built for 14 x 14 x 320 with an 80-channel squeeze and an 80-channel gated-shift slice");
+    STES_CHECK(a->C == BE_C && a->H == BE_W && a->W == BE_W && a->rd == BE_RD && (a->fold == BE_FOLD || a->fold == 0), STES_ERR_UNSUPPORTED,
+               "stes_block_eval_s3: built for 14 x 14 x 320 with an 80-channel squeeze and an 80-channel gated-shift slice (or none)");
     STES_CHECK(!a->slice || (a->slice_n > 0 && a->slice_n % 8 == 0 && a->slice_n <= BE_C), STES_ERR_ARG, "stes_block_eval_s3: slice width");
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_eval_s3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     160 * 1024) == hipSuccess;

@@ -198,8 +198,8 @@ class Block:
                 lib.call("stes_tsm_shift", p(X), p(self.Xs), self.tsm_fold, cin, self.N // self.T, self.T, self.Hi, self.Wi, 0)
                 a_src = self.Xs
         self.a_src = a_src
-        if (not train and e.block_fused and self.kind == "gsm" and cin == cmid == cout
-                and lib.block_eval_takes(cmid, self.Hi, self.Wi, self.rd, self.fold, self.stride, self.down)):
+        if (not train and e.block_fused and cin == cmid == cout and self.l1.Kp == cin
+                and lib.block_eval_takes(cmid, self.Hi, self.Wi, self.rd, k0, self.stride, self.down)):
             # evaluation, stage-3 identity blocks: every BatchNorm is a fixed affine map and one 14x14 image's activations fit
             # a compute unit's LDS, so the three convolutions and the squeeze-excite run per image in one kernel and only the
             # block input and output touch memory (c1, c2 and the pooled/hidden/gate vectors never exist)
@@ -207,7 +207,7 @@ class Block:
                 bn.finalize(Mo, train)
             slc = (nxt.Xc, nxt.fold) if nxt is not None and nxt.kind == "gsm" else (None, 0)
             se = self.se
-            lib.block_eval(X, self.G, self.l1.w_bf, (self.bn1.scale, self.bn1.shift), self.wp2_f, (self.bn2.scale, self.bn2.shift),
+            lib.block_eval(a_src, a0, self.l1.w_bf, (self.bn1.scale, self.bn1.shift), self.wp2_f, (self.bn2.scale, self.bn2.shift),
                            self.se1.w_bf, se.fc1.bias, self.se2.w_bf, se.fc2.bias, self.l3.w_bf, (self.bn3.scale, self.bn3.shift),
                            self.out, slc[0], slc[1], self.N)
             return self.out

@@ -478,7 +478,7 @@ def block_front(X, G, fold, W1, bn1, wp2, bn2, c2, pooled, N, H, W, cin, cmid, s
 def block_eval_takes(C_, H, W, rd, fold, stride, down):
     """Shapes for which stes_block_eval_s3 runs a whole bottleneck's evaluation forward in one kernel (the rule in
     stes_block_eval.hip: RegNet-Y 800MF's stage-3 identity blocks)."""
-    return (C_, H, W, rd, fold, stride) == (320, 14, 14, 80, 80, 1) and not down
+    return (C_, H, W, rd, stride) == (320, 14, 14, 80, 1) and fold in (0, 80) and not down
 
 
 def block_eval(X, G, W1, bn1, wp2, bn2, Wse1, bse1, Wse2, bse2, W3, bn3, out, slc, slice_n, N):
@@ -490,11 +490,11 @@ def block_eval(X, G, W1, bn1, wp2, bn2, Wse1, bse1, Wse2, bse2, W3, bn3, out, sl
     a.Wse1, a.bse1, a.Wse2, a.bse2 = ptr(Wse1), ptr(bse1), ptr(Wse2), ptr(bse2)
     a.W3, a.s3, a.b3 = ptr(W3), ptr(bn3[0]), ptr(bn3[1])
     a.out, a.slice, a.slice_n = ptr(out), ptr(slc), slice_n
-    a.N, a.H, a.W, a.C, a.rd, a.fold = N, 14, 14, 320, 80, 80
+    a.N, a.H, a.W, a.C, a.rd, a.fold = N, 14, 14, 320, 80, (80 if G is not None else 0)
     fn = lambda: check(lib().stes_block_eval_s3(C.byref(a), stream()), "stes_block_eval_s3")
     if TIMING is not None:
         m = N * 196
-        _timed("block_eval_s3_kernel", 2 * m * (320 + 80 + 320 + slice_n), 2 * m * (2 * 320 * 320 + 320 * 144), fn)     # (X counted once: its second read for the shortcut is not algorithmic)
+        _timed("block_eval_s3_kernel", 2 * m * (320 + a.fold + 320 + slice_n), 2 * m * (2 * 320 * 320 + 320 * 144), fn)     # (X counted once: its second read for the shortcut is not algorithmic)
         return
     fn()
 

@@ -64,11 +64,11 @@ def test_eval_forward_vs_reference_golden(golden):
     np.testing.assert_allclose(loc, oloc, atol=2e-2)
 
 
-@pytest.mark.parametrize("arch,tarch,n_blocks", [("rny008_gsm", "gru", 7), ("rny008_tsm", "mingru", 0), ("rny008", "gru", 0)])
+@pytest.mark.parametrize("arch,tarch,n_blocks", [("rny008_gsm", "gru", 7), ("rny008_tsm", "mingru", 7), ("rny008", "gru", 7)])
 def test_eval_forward_224_fused_stage3_blocks_match_the_kernel_sequence(arch, tarch, n_blocks):
-    """At 224 x 224 the seven identity bottlenecks of stage 3 (14 x 14 x 320) of the gated-shift network run as one kernel each in
-    evaluation mode (stes_block_eval_s3), and conv1 + conv2 of the blocks of stages 1 and 2 as one kernel each in every variant
-    (stes_block_front_eval; without a gated shift there is no substituted slice).  Same model, same clip, with those paths on and
+    """At 224 x 224 the seven identity bottlenecks of stage 3 (14 x 14 x 320) run as one kernel each in evaluation mode
+    (stes_block_eval_s3), and conv1 + conv2 of the blocks of stages 1 and 2 as one kernel each (stes_block_front_eval), in every
+    variant (without a gated shift there is no substituted slice).  Same model, same clip, with those paths on and
     off: the features agree to bf16 rounding noise (both paths round at the same points; fp32 summation order differs), far
     inside the 1e-2 stated against fp32."""
     from spot_amd import lib
