@@ -97,7 +97,7 @@ typedef struct {
 int stes_gemm(const stes_gemm_args* a, void* stream);
 
 /* Evaluation forward of the front half of a bottleneck of stages 1 and 2 of RegNet-Y 800MF (stride 2: 112 x 112 x 32 -> 64 channels
- * -> 56 x 56, and 56 x 56 x 64 -> 128 channels -> 28 x 28; stride 1: 28 x 28 x 128 -> 128 channels) in ONE kernel: conv1 (1x1, the
+ * -> 56 x 56, 56 x 56 x 64 -> 128 channels -> 28 x 28 and 28 x 28 x 128 -> 320 channels -> 14 x 14; stride 1: 28 x 28 x 128 -> 128 channels) in ONE kernel: conv1 (1x1, the
  * gated shift's result G in place of the first `fold` input channels, reference model/shift.py:157-161; fold may be 0) -> bn1 +
  * ReLU -> grouped 3x3 conv2 with the given stride -> raw c2 [N*(H/stride)*(W/stride)][Cmid] and the squeeze-excite squeeze pooled [N][Cmid] = mean relu(bn2(c2)) (timm Bottleneck,
  * train_e2e_spatial.py:305-314; evaluation-mode BatchNorms).  conv1's output, at the block's input resolution the largest tensor

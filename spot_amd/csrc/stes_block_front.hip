@@ -1,5 +1,6 @@
 // Evaluation forward of the front half of a bottleneck of stages 1 and 2 (RegNet-Y 800MF s1.b1: 112 x 112 x 32 -> 64 channels
-// -> 56 x 56; s2.b1: 56 x 56 x 64 -> 128 channels -> 28 x 28; s2.b2 / s2.b3: 28 x 28 x 128 -> 128 channels, stride 1) in one kernel: conv1 (1x1, with the gated shift's result
+// -> 56 x 56; s2.b1: 56 x 56 x 64 -> 128 channels -> 28 x 28; s2.b2 / s2.b3: 28 x 28 x 128 -> 128 channels, stride 1; s3.b1:
+// 28 x 28 x 128 -> 320 channels -> 14 x 14) in one kernel: conv1 (1x1, with the gated shift's result
 // G substituted for the first `fold` input channels, model/shift.py:157-161) -> bn1 + ReLU -> grouped 3x3 conv2 (stride 2 or 1)
 // -> raw c2 and the squeeze-excite squeeze mean_hw relu(bn2(c2)) (timm Bottleneck as the reference builds it,
 // train_e2e_spatial.py:305-314; BatchNorms in evaluation mode).  conv1 runs at the block's INPUT resolution, so its output is
@@ -37,42 +38,57 @@ __device__ __forceinline__ f_s16x4 bf_tap_frag(const bf16* __restrict__ wp, int 
 }
 
 // STRIDE: conv2's stride (2: the first block of a stage, 1: the others); NSPLIT: conv1's output channels are dealt to this many
-// wave groups (2 where a row has too few pixel tiles to occupy four waves)
-template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
+// wave groups (2 where a row has too few pixel tiles to occupy four waves); WLDS: conv1's weights live in LDS in fragment order
+// instead of registers (s3.b1: 80 KB), and the ring has three slots instead of four (the two rows a step brings replace the two
+// oldest ones, which the barrier after the convolution has released)
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT, bool WLDS>
 struct FrontShape {
     static constexpr int NT = CMID / 16, NTW = NT / NSPLIT, KS = CIN / 32, WO = WI / STRIDE, CT = (WI + 15) / 16, CF = (WO + 15) / 16;
     // ring: elements per pixel; the padding puts two lanes' pixels (STRIDE pixels apart) four banks apart for the 8-byte reads
     static constexpr int PXS = CMID + (STRIDE == 2 ? 4 : 8);
     static constexpr int SLOT = (WI + 2) * PXS;            // a row slot with a zero pixel either side
+    static constexpr int NSLOT = WLDS ? 3 : 4;
+    static constexpr int WEL = WLDS ? NT * KS * 64 * 8 : 0; // elements of the weight image in LDS
     static constexpr int SPX = CMID + 8;                   // staging row: elements per pixel (16-byte chunks stay aligned)
     static constexpr int GPW = CMID / 64;                  // 16-channel groups per wave
+    static_assert(CMID % 64 == 0 && (!WLDS || STRIDE == 2), "groups per wave; three slots need two new rows per step");
     static constexpr int UNITS = STRIDE * CT * NSPLIT, UPW = (UNITS + 3) / 4;      // (pixel tile, channel share) units of a step
-    static constexpr size_t LDS = (size_t)(4 * SLOT + WO * SPX) * 2 + 4 * CMID * sizeof(float);
+    static constexpr size_t LDS = (size_t)(NSLOT * SLOT + WO * SPX + WEL) * 2 + 4 * CMID * sizeof(float);
     static_assert(NT % NSPLIT == 0 && (NSPLIT == 1 || NSPLIT == 2), "channel shares");
 };
 
-template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_front_args p) {
-    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT> S;
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT, bool WLDS>
+__global__ __launch_bounds__(256, (WLDS ? 1 : 2)) void block_front_kernel(const stes_block_front_args p) {
+    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT, WLDS> S;
     extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
-    bf16* ring = reinterpret_cast<bf16*>(bf_smem);                          // [4][SLOT]
-    bf16* stage = ring + 4 * S::SLOT;                                       // [WO][SPX]
-    float* cst = reinterpret_cast<float*>(stage + S::WO * S::SPX);
+    bf16* ring = reinterpret_cast<bf16*>(bf_smem);                          // [NSLOT][SLOT]
+    bf16* stage = ring + S::NSLOT * S::SLOT;                                // [WO][SPX]
+    bf16* wl = stage + S::WO * S::SPX;                                      // [NT][KS][64 lanes][8] when WLDS
+    float* cst = reinterpret_cast<float*>(wl + S::WEL);
     float* s1 = cst, *b1 = cst + CMID, *s2 = cst + 2 * CMID, *b2 = cst + 3 * CMID;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int HI = p.H, HO = HI / STRIDE, fold = p.fold;
     const bf16* __restrict__ X = (const bf16*)p.X;
     const bf16* __restrict__ G = (const bf16*)p.G;
     for (int i = tid; i < CMID; i += 256) { s1[i] = p.s1[i]; b1[i] = p.b1[i]; s2[i] = p.s2[i]; b2[i] = p.b2[i]; }
-    for (int i = tid; i < 4 * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // borders stay zero for good
+    for (int i = tid; i < S::NSLOT * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // borders stay zero for good
     // conv1's weights of this wave's channel share: fragment (j, ks) = output channels 16 (nt0 + j).., input channels 32ks..
     const int nt0 = (wave % NSPLIT) * S::NTW;
-    bf16x8 wf[S::NTW][S::KS];
+    bf16x8 wf[WLDS ? 1 : S::NTW][WLDS ? 1 : S::KS];
+    if (WLDS) {
+        // fragment (j, ks) as 64 consecutive 16-byte pieces, one per lane: every wave reads its operands with conflict-free b128s
+        for (int i = tid; i < S::NT * S::KS * 64; i += 256) {
+            const int l = i & 63, f = i >> 6, j = f / S::KS, ks = f - j * S::KS;
+            *reinterpret_cast<bf16x8*>(wl + (long)i * 8) =
+                *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)(16 * j + (l & 15)) * CIN + 32 * ks + 8 * (l >> 4));
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < S::NTW; ++j)
+        for (int j = 0; j < S::NTW; ++j)
 #pragma unroll
-        for (int ks = 0; ks < S::KS; ++ks)
-            wf[j][ks] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)(16 * (nt0 + j) + fr) * CIN + 32 * ks + 8 * fq);
+            for (int ks = 0; ks < S::KS; ++ks)
+                wf[WLDS ? 0 : j][WLDS ? 0 : ks] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)(16 * (nt0 + j) + fr) * CIN + 32 * ks + 8 * fq);
+    }
     // conv2's taps of this wave's groups
     f_s16x4 wA[S::GPW][3][3];
 #pragma unroll
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
                 }
             }
             if (ro == HO) break;
-            // (a) the step's new conv1 rows into their ring slots (row r lives in slot (r + 1) & 3; a row below the image is zeros)
+            // (a) the step's new conv1 rows into their ring slots (row r lives in slot (r + 1) mod NSLOT; a row below the image is zeros)
 #pragma unroll
             for (int i = 0; i < S::UPW; ++i) {
                 const int u = wave + 4 * i;
@@ -155,10 +171,13 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
 #pragma unroll
                 for (int ks = 0; ks < S::KS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < S::NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[j], 0, 0, 0);
+                    for (int j = 0; j < S::NTW; ++j) {
+                        const bf16x8 w = WLDS ? *reinterpret_cast<const bf16x8*>(wl + ((long)((nt0 + j) * S::KS + ks) * 64 + lane) * 8) : wf[WLDS ? 0 : j][WLDS ? 0 : ks];
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, af[i][ks], acc[j], 0, 0, 0);
+                    }
                 const int px = 16 * ct + fr;
                 if (px < WI) {
-                    bf16* dstp = ring + ((r + 1) & 3) * S::SLOT + (px + 1) * S::PXS + 16 * nt0 + 4 * fq;
+                    bf16* dstp = ring + ((r + 1) % S::NSLOT) * S::SLOT + (px + 1) * S::PXS + 16 * nt0 + 4 * fq;
                     const bool inside = STRIDE == 2 || r < HI;
 #pragma unroll
                     for (int j = 0; j < S::NTW; ++j) {
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
             }
             __syncthreads();
             if (ro < 0) continue;                                           // (stride 1: the step that only brings row 0)
-            // (b) output row ro: source rows STRIDE ro - 1 + a = slots (STRIDE ro + a) & 3
+            // (b) output row ro: source rows STRIDE ro - 1 + a = slots (STRIDE ro + a) mod NSLOT
 #pragma unroll
             for (int gi = 0; gi < S::GPW; ++gi) {
                 const int g = wave + 4 * gi, ch0 = g * 16 + 4 * fq;
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
                 for (int f = 0; f < S::CF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const bf16* row = ring + ((STRIDE * ro + a) & 3) * S::SLOT + ch0;
+                    const bf16* row = ring + ((STRIDE * ro + a) % S::NSLOT) * S::SLOT + ch0;
 #pragma unroll
                     for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -232,21 +251,21 @@ __global__ __launch_bounds__(256, 2) void block_front_kernel(const stes_block_fr
     }
 }
 
-template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT>
+template <int CIN, int CMID, int WI, int STRIDE, int NSPLIT, bool WLDS = false>
 int front_launch(const stes_block_front_args* a, void* stream) {
-    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT> S;
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>),
+    typedef FrontShape<CIN, CMID, WI, STRIDE, NSPLIT, WLDS> S;
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT, WLDS>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     STES_CHECK(big_lds, STES_ERR_UNSUPPORTED, "stes_block_front_eval: cannot raise the dynamic LDS limit");
     static int resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT, WLDS>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = per_cu * (cus < 1 ? 256 : cus);
     }
     const int grid = a->N < resident ? a->N : resident;
-    hipLaunchKernelGGL((block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT>), dim3(grid), dim3(256), S::LDS, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((block_front_kernel<CIN, CMID, WI, STRIDE, NSPLIT, WLDS>), dim3(grid), dim3(256), S::LDS, (hipStream_t)stream, *a);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -262,6 +281,7 @@ extern "C" int stes_block_front_eval(const stes_block_front_args* a, void* strea
     if (a->stride == 2 && a->Cin == 32 && a->Cmid == 64 && a->W == 112) return front_launch<32, 64, 112, 2, 1>(a, stream);
     if (a->stride == 2 && a->Cin == 64 && a->Cmid == 128 && a->W == 56) return front_launch<64, 128, 56, 2, 1>(a, stream);
     if (a->stride == 1 && a->Cin == 128 && a->Cmid == 128 && a->W == 28) return front_launch<128, 128, 28, 1, 2>(a, stream);
-    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_block_front_eval: built for 112 x 112 x 32 -> 64 and 56 x 56 x 64 -> 128 channels with "
-                                                "stride 2 and 28 x 28 x 128 -> 128 channels with stride 1");
+    if (a->stride == 2 && a->Cin == 128 && a->Cmid == 320 && a->W == 28) return front_launch<128, 320, 28, 2, 1, true>(a, stream);
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_block_front_eval: built for 112 x 112 x 32 -> 64, 56 x 56 x 64 -> 128 and 28 x 28 x 128 -> 320 channels "
+                                                "with stride 2 and 28 x 28 x 128 -> 128 channels with stride 1");
 }

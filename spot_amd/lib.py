@@ -454,8 +454,8 @@ def gemm2(A, W1, H, W2, Cout, M, K1, N1, N2, *, bias1=None, act1=0, relu_mask1=N
 
 def block_front_takes(cin, cmid, H, W, stride, fold):
     """Shapes for which stes_block_front_eval runs conv1 -> bn/act -> conv2 (+ squeeze) of a bottleneck in one kernel (the rule
-    in stes_block_front.hip: RegNet-Y 800MF's s1.b1, s2.b1 and the identity blocks of stage 2)."""
-    return H == W and (stride, cin, cmid, W) in ((2, 32, 64, 112), (2, 64, 128, 56), (1, 128, 128, 28)) and fold % 8 == 0 and fold <= 32
+    in stes_block_front.hip: RegNet-Y 800MF's s1.b1, s2.b1, s3.b1 and the identity blocks of stage 2)."""
+    return H == W and (stride, cin, cmid, W) in ((2, 32, 64, 112), (2, 64, 128, 56), (1, 128, 128, 28), (2, 128, 320, 28)) and fold % 8 == 0 and fold <= 32
 
 
 def block_front(X, G, fold, W1, bn1, wp2, bn2, c2, pooled, N, H, W, cin, cmid, stride):

@@ -303,7 +303,8 @@ def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
 
 
 @pytest.mark.parametrize("N,cin,cmid,Wd,fold,stride", [(5, 32, 64, 112, 8, 2), (9, 64, 128, 56, 16, 2), (600, 64, 128, 56, 16, 2), (3, 32, 64, 112, 0, 2),
-                                                        (11, 128, 128, 28, 32, 1), (900, 128, 128, 28, 32, 1), (2, 128, 128, 28, 0, 1)])
+                                                        (11, 128, 128, 28, 32, 1), (900, 128, 128, 28, 32, 1), (2, 128, 128, 28, 0, 1),
+                                                        (7, 128, 320, 28, 32, 2), (700, 128, 320, 28, 32, 2), (3, 128, 320, 28, 0, 2)])
 def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold, stride):
     """conv1 -> bn1/ReLU -> grouped conv2 (+ squeeze) of a bottleneck in one kernel against stes_gemm followed by
     stes_conv3x3g_fwd_pool: same roundings, so c2 agrees to fp32 summation order (an odd bf16 ulp) and the squeeze to its bf16

@@ -88,7 +88,7 @@ def test_eval_forward_224_fused_stage3_blocks_match_the_kernel_sequence(arch, ta
             fronts = sum(1 for rec in lib.TIMING if rec[0].startswith("block_front"))
         finally:
             lib.TIMING = None
-        assert launches == (n_blocks if fused else 0) and fronts == (4 if fused else 0), (launches, fronts)
+        assert launches == (n_blocks if fused else 0) and fronts == (5 if fused else 0), (launches, fronts)
         out[fused] = {k: d[k].float().cpu() for k in ("cnn_feat", "im_feat", "loc_feat")}
     eng.block_fused = True
     for k in out[True]:

@@ -29,7 +29,7 @@ def timed(fn, reps=10):
 def main():
     N = 1024
     g = torch.Generator().manual_seed(0)
-    for cin, cmid, wd, fold, stride in ((32, 64, 112, 8, 2), (64, 128, 56, 16, 2), (128, 128, 28, 32, 1)):
+    for cin, cmid, wd, fold, stride in ((32, 64, 112, 8, 2), (64, 128, 56, 16, 2), (128, 128, 28, 32, 1), (128, 320, 28, 32, 2)):
         M = N * wd * wd
         Mo = M // (stride * stride)
         X = torch.randn(M, cin, generator=g).abs().to(BF).cuda()
