@@ -79,6 +79,34 @@ def test_eval_forward_on_small_maps_with_many_frames_vs_oracle():
     assert rel(d1["im_feat"].cpu(), d["im_feat"][:1].cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("arch,tarch", [("rny008_gsm", "gru"), ("rny008_tsm", "mingru")])
+def test_eval_forward_at_224_with_the_fused_blocks_vs_oracle(arch, tarch):
+    """224 x 224 is where the evaluation forward runs its fused kernels (stes_block_front_eval for the first blocks of stages
+    1-3 and the identity blocks of stage 2, stes_block_eval_s3 for the identity blocks of stage 3): the whole model against the
+    CPU oracle in fp32, at the tolerance stated for the evaluation forward."""
+    from spot_amd import lib
+    om, m = _pair(arch, tarch, clip_len=4, seed=31)
+    x = torch.randn(1, 4, 3, 224, 224, generator=torch.Generator().manual_seed(32))
+    torch.set_num_threads(16)
+    om.eval()
+    with torch.no_grad():
+        od = om(x)
+    m._model.eval()
+    lib.TIMING = []
+    try:
+        with torch.no_grad():
+            d = m._model(x.cuda())
+        torch.cuda.synchronize()
+        fused = sorted(set(rec[0].split("<")[0] for rec in lib.TIMING if rec[0].startswith("block_")))
+    finally:
+        lib.TIMING = None
+    assert fused == ["block_eval_s3_kernel", "block_front_kernel"], fused
+    for k in ("cnn_feat", "im_feat", "loc_feat"):
+        r = rel(d[k].cpu(), od[k])
+        print(k, r)
+        assert r < (2.5e-2 if k == "loc_feat" else 1e-2), (k, r)
+
+
 def test_deeper_gru_eval_vs_oracle():
     from oracle import stes_oracle as O
     om, m = _pair("rny008_gsm", "deeper_gru")
