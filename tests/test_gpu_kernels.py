@@ -286,7 +286,7 @@ def test_block_in_grad_takes_the_adjoint_temporal_shift_on_its_way(B, T, H, W, C
         close(a.cpu(), b.cpu(), 1e-5, 1e-4)
 
 
-@pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 3, 4, 32, 4), (1, 8, 2, 2, 64, 8), (3, 19, 1, 5, 320, 40), (1, 1, 2, 3, 32, 4), (2, 64, 7, 7, 768, 96)])
+@pytest.mark.parametrize("B,T,H,W,Cc,fold", [(2, 5, 3, 4, 32, 4), (1, 8, 2, 2, 64, 8), (3, 19, 1, 5, 320, 40), (1, 1, 2, 3, 32, 4), (2, 64, 7, 7, 768, 96), (2, 2, 3, 3, 64, 8), (1, 9, 5, 5, 128, 16)])
 def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
     """The temporal shift (reference model/shift.py:37-52) applied in place -- only the moving channels are touched, frames walked
     in the direction the values come from -- against the out-of-place kernel, forward and adjoint, bit for bit."""
@@ -304,7 +304,8 @@ def test_tsm_shift_in_place_equals_the_copying_shift(B, T, H, W, Cc, fold):
 
 @pytest.mark.parametrize("N,cin,cmid,Wd,fold,stride", [(5, 32, 64, 112, 8, 2), (9, 64, 128, 56, 16, 2), (600, 64, 128, 56, 16, 2), (3, 32, 64, 112, 0, 2),
                                                         (11, 128, 128, 28, 32, 1), (900, 128, 128, 28, 32, 1), (2, 128, 128, 28, 0, 1),
-                                                        (7, 128, 320, 28, 32, 2), (700, 128, 320, 28, 32, 2), (3, 128, 320, 28, 0, 2)])
+                                                        (7, 128, 320, 28, 32, 2), (700, 128, 320, 28, 32, 2), (3, 128, 320, 28, 0, 2),
+                                                        (1, 32, 64, 112, 8, 2), (1, 128, 128, 28, 32, 1), (1, 128, 320, 28, 32, 2)])
 def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold, stride):
     """conv1 -> bn1/ReLU -> grouped conv2 (+ squeeze) of a bottleneck in one kernel against stes_gemm followed by
     stes_conv3x3g_fwd_pool: same roundings, so c2 agrees to fp32 summation order (an odd bf16 ulp) and the squeeze to its bf16
@@ -337,7 +338,7 @@ def test_block_front_eval_equals_the_kernel_sequence(N, cin, cmid, Wd, fold, str
     close(pool.float().cpu(), ref_pool.float().cpu(), 1e-2, 1e-2)
 
 
-@pytest.mark.parametrize("N,with_slice,fold", [(43, True, 80), (300, False, 80), (45, False, 0)])
+@pytest.mark.parametrize("N,with_slice,fold", [(43, True, 80), (300, False, 80), (45, False, 0), (257, True, 80), (513, False, 0)])
 def test_block_eval_s3_equals_the_kernel_sequence(N, with_slice, fold):
     """A stage-3 bottleneck's evaluation forward in one kernel against the sequence it replaces (stes_gemm with the gated-shift
     split, stes_conv3x3g_fwd_pool, stes_gemm_small2, stes_gemm with the block-tail epilogue): same roundings, so the results
