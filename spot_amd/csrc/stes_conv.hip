@@ -12,6 +12,7 @@
 #include <mutex>
 #include "stes_common.h"
 #include "stes_conv_strip.h"
+#include "stes_conv_ring.h"
 
 namespace {
 
@@ -1108,6 +1109,10 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     if (stes_conv_strip_takes(mode, stride, Wi))         // 14 x 14 and 7 x 7 maps, forward: operands straight from memory, no LDS window
         return stes_conv_strip_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream, pool_scale, pool_shift, pool_out,
                                       pool_norm);
+    if (stes_conv_ring_takes(mode, stride, Hi, Wi, pool_out != nullptr))     // the strided forward of the large maps: read-each-pixel-2.25-times ring
+        return stes_conv_ring_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
+    if (stes_dgrad_ring_takes(mode, stride, Hi, Wi))
+        return stes_dgrad_ring_launch(src, wp, dst, mask_raw, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
     if (mode == 0 || stride == 1) {
         // LDS row-ring kernel when its ring + staging fit
         RowsGeom rg;

@@ -1,0 +1,15 @@
+// Grouped 3x3 convolution with stride 2, forward (stes_conv_ring.hip): an image's input rows walk through a ring of row slots in
+// LDS and every output row is convolved from three of them; called by stes_conv3x3g_fwd for the map widths it is built for.
+#pragma once
+#include <stdint.h>
+
+bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled);
+// Returns STES_OK or a negative error code.
+int stes_conv_ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
+                          float* col_sumsq, int N, int Hi, int Wi, int C, void* stream);
+
+// The input gradient of the same convolution (Hi x Wi = the gradient's map), with the ReLU mask and BatchNorm sums of
+// stes_conv3x3g_dgrad when mask_raw is given.
+bool stes_dgrad_ring_takes(int mode, int stride, int Hi, int Wi);
+int stes_dgrad_ring_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx, const uint16_t* mask_raw, const float* mscale,
+                           const float* mshift, float* s_dy, float* s_dyr, int N, int Hi, int Wi, int C, void* stream);

@@ -1,0 +1,448 @@
+// Grouped 3x3 convolution (groups of 16 channels) with stride 2, forward, for the first block of a stage (timm Bottleneck conv2
+// as the reference builds it, train_e2e_spatial.py:305-314): input = raw output of the convolution in front, BatchNorm + ReLU
+// applied on the way in; output raw, with its per-channel sum and sum of squares for the BatchNorm behind it.
+// A workgroup (4 waves) owns 64 channels (grouped convolution never mixes them, so a pixel's 128 bytes are whole cache lines)
+// and walks an image's output rows.  Per output row ro:
+//   (a) input rows 2ro and 2ro+1 come from memory as 16-byte chunks (requested two steps ahead), are transformed and go to a
+//       ring of four row slots in LDS (row 2ro-1 is there from the step before, row -1 is zeros; a zero pixel either side);
+//   (b) the output row is convolved from three slots: wave = group, lane = output column, nine K = 16 MFMAs per 16-column
+//       fragment on 8-byte LDS reads -- with stride 2 an input pixel is read 2.25 times, against ten times for an im2col
+//       operand -- (pixel stride padded by 8 bytes: two pixels apart is four banks apart); the result leaves through a
+//       staging row as 16-byte chunks; the statistics are summed in registers over all the workgroup's images and committed
+//       once (one atomic per channel and workgroup).
+#include "stes_common.h"
+#include "stes_conv_ring.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef short r_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned r_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned r_u32x4 __attribute__((ext_vector_type(4)));
+#define CR_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float cr_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+// A operand of one tap from the k-step-pair pack of stes_pack_conv3x3g ([G][5][64][8])
+__device__ __forceinline__ r_s16x4 cr_tap_frag(const bf16* __restrict__ wp, int g, int slot, int lane) {
+    const int m = lane & 15, q = lane >> 4;
+    const int packed_lane = ((slot & 1) * 2 + (q >> 1)) * 16 + m;
+    return *reinterpret_cast<const r_s16x4*>(wp + (((long)g * 5 + (slot >> 1)) * 64 + packed_lane) * 8 + 4 * (q & 1));
+}
+
+template <int WI>
+struct RingShape {
+    static constexpr int WO = WI / 2, CF = (WO + 15) / 16;
+    static constexpr int PXS = 64 + 4;                      // ring: elements per pixel (8 bytes of padding)
+    static constexpr int SLOT = (WI + 2) * PXS;             // a row slot with a zero pixel either side
+    static constexpr int SPX = 64 + 8;                      // staging row: elements per pixel
+    static constexpr int CHUNKS = 2 * WI * 8, CPT = (CHUNKS + 255) / 256;      // 16-byte chunks of a step's two input rows
+    static constexpr size_t LDS = (size_t)(4 * SLOT + WO * SPX) * 2;
+};
+
+template <int WI>
+__global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict__ in, const bf16* __restrict__ wp, bf16* __restrict__ out,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* col_sum, float* col_sumsq, int N, int HI, int C, StesDet det) {
+    typedef RingShape<WI> S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
+    bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [4][SLOT]
+    bf16* stage = ring + 4 * S::SLOT;                                       // [WO][SPX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int HO = HI / 2, slice = blockIdx.y, cb = slice * 64;
+    for (int i = tid; i < 4 * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // borders stay zero for good
+    r_s16x4 wA[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wA[a][b] = cr_tap_frag(wp, slice * 4 + wave, a * 3 + b, lane);
+    // the input transform of this thread's eight channels (a thread's chunks all have channel piece tid & 7)
+    const int chunk = tid & 7;
+    const bool affine = scale != nullptr;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = affine ? scale[cb + chunk * 8 + e] : 1.f; sh[e] = affine ? shift[cb + chunk * 8 + e] : 0.f; }
+    const int ch0 = wave * 16 + 4 * fq;                                     // this lane's output channels within the slice
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // the workgroup's steps (image, output row) in one sequence, input rows requested two steps ahead -- across images too
+    const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int total = nimg * HO;
+    int fn = blockIdx.x, fro = 0;                                           // the step the next request is for
+    auto fetch = [&](bf16x8 (&dst)[S::CPT]) {
+        if (fn < N) {
+            const bf16* src = in + ((long)fn * HI + 2 * fro) * WI * C + cb + chunk * 8;
+#pragma unroll
+            for (int k = 0; k < S::CPT; ++k) {
+                const int i = tid + 256 * k;                                // chunk i: pixel i >> 3 of the two-row strip
+                if (i < S::CHUNKS) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
+            }
+        }
+        if (++fro == HO) { fro = 0; fn += gridDim.x; }
+    };
+    int n = blockIdx.x, ro = 0, pn = 0, pro = -1;                           // this step, the step before
+    auto step = [&](bf16x8 (&raw)[S::CPT]) {
+        if (pro >= 0) {                                                     // the staged output row of the step before leaves as whole chunks
+            bf16* dst = out + (((long)pn * HO + pro) * S::WO) * C + cb;
+            for (int idx = tid; idx < S::WO * 8; idx += 256) {
+                const int co = idx >> 3, c0 = (idx & 7) * 8;
+                *reinterpret_cast<bf16x8*>(dst + (long)co * C + c0) = *reinterpret_cast<const bf16x8*>(stage + co * S::SPX + c0);
+            }
+        }
+        if (ro == 0) {                                                      // row -1 of an image: zeros (slot 0 holds rows 3, 7, .. later)
+            for (int i = tid; i < WI * 32; i += 256) reinterpret_cast<unsigned*>(ring + ((i >> 5) + 1) * S::PXS)[i & 31] = 0u;
+        }
+        // (a) rows 2ro and 2ro+1, transformed, into their slots (row r lives in slot (r + 1) & 3)
+#pragma unroll
+        for (int k = 0; k < S::CPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::CHUNKS) {
+                const int p = i >> 3, row = p >= WI ? 1 : 0, px = p - row * WI;
+                bf16x8 v = raw[k];
+                if (affine) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f);
+                }
+                const r_u32x4 w = __builtin_bit_cast(r_u32x4, v);
+                bf16* dstp = ring + ((2 * ro + row + 1) & 3) * S::SLOT + (px + 1) * S::PXS + chunk * 8;
+                *reinterpret_cast<r_u32x2*>(dstp) = (r_u32x2){w[0], w[1]};
+                *reinterpret_cast<r_u32x2*>(dstp + 4) = (r_u32x2){w[2], w[3]};
+            }
+        }
+        fetch(raw);                                                         // the rows of two steps on
+        __syncthreads();
+        // (b) output row ro: source rows 2ro-1, 2ro, 2ro+1 = slots (2ro + a) & 3
+        f32x4 acc[S::CF];
+#pragma unroll
+        for (int f = 0; f < S::CF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bf16* row = ring + ((2 * ro + a) & 3) * S::SLOT + ch0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int f = 0; f < S::CF; ++f) {
+                    const int pxi = min(2 * (16 * f + fr) + b, WI + 1);      // ring pixel index of column 2co + b - 1
+                    const r_u32x2 rawb = *reinterpret_cast<const r_u32x2*>(row + pxi * S::PXS);
+                    acc[f] = CR_MFMA16(wA[a][b], __builtin_bit_cast(r_s16x4, rawb), acc[f]);
+                }
+        }
+#pragma unroll
+        for (int f = 0; f < S::CF; ++f) {
+            const int co = 16 * f + fr;
+            if (co < S::WO) {
+                bf16x4 ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[f][e];
+                *reinterpret_cast<bf16x4*>(stage + co * S::SPX + ch0) = ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float fv = (float)ob[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+            }
+        }
+        __syncthreads();
+        pn = n; pro = ro;
+        if (++ro == HO) { ro = 0; n += gridDim.x; }
+    };
+    bf16x8 rawA[S::CPT], rawB[S::CPT];
+    fetch(rawA);
+    fetch(rawB);
+#pragma unroll 1
+    for (int s = 0; s < total; s += 2) {
+        step(rawA);
+        if (s + 1 < total) step(rawB);
+    }
+    if (pro >= 0) {
+        bf16* dst = out + (((long)pn * HO + pro) * S::WO) * C + cb;
+        for (int idx = tid; idx < S::WO * 8; idx += 256) {
+            const int co = idx >> 3, c0 = (idx & 7) * 8;
+            *reinterpret_cast<bf16x8*>(dst + (long)co * C + c0) = *reinterpret_cast<const bf16x8*>(stage + co * S::SPX + c0);
+        }
+    }
+    if (col_sum) {
+        // one 64-lane atomic per workgroup and array (a lane per channel): the workgroups end together and their additions to
+        // the same 64 addresses queue up at the L2, so every instruction less is time off the kernel's tail
+        float* red = reinterpret_cast<float*>(stage);                       // [2][64]
+        __syncthreads();
+        float a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = cr_row16_sum(ssum[e]); b[e] = cr_row16_sum(ssq[e]); }
+        if (fr == 0) {
+            *reinterpret_cast<f32x4*>(red + ch0) = (f32x4){a[0], a[1], a[2], a[3]};
+            *reinterpret_cast<f32x4*>(red + 64 + ch0) = (f32x4){b[0], b[1], b[2], b[3]};
+        }
+        __syncthreads();
+        det_enter(det);
+        if (wave == 0) {
+            atomicAdd(col_sum + cb + lane, red[lane]);
+            atomicAdd(col_sumsq + cb + lane, red[64 + lane]);
+        }
+        det_leave(det);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- input gradient
+// dX of the same convolution: dX[h][w] gathers dY[(h + 1 - a) / 2][(w + 1 - b) / 2] over the taps (a, b) whose parities
+// match, so the 2 x 2 output pixels under dY pixel (y, j) take 1, 2, 2 and 4 taps -- nine K = 16 MFMAs on four 8-byte reads
+// (dY pixels j and j + 1 of rows y and y + 1), nothing multiplied by zero.  The walk is the forward kernel's: per step one new
+// dY row enters a ring of three slots (a zero pixel at the right, a zero row after the last), two output rows are staged
+// (even and odd columns in planes of their own: lane = j writes without bank conflicts) and leave as 16-byte chunks, on the
+// way masked by the ReLU in front (raw input of that ReLU and its BatchNorm affine given) and summed for the BatchNorm
+// backward: s_dy += dX, s_dyr += dX * raw.  dY rows and the raw rows under the mask are requested two steps ahead.
+template <int WI>
+struct DgradShape {
+    static constexpr int WO = WI / 2, CF = (WO + 15) / 16;
+    static constexpr int PXS = 64 + 8;                      // elements per pixel, ring and staging: 36 banks, so the 32 lanes
+                                                            // of an 8-byte access pass fall on 32 different bank pairs
+    static constexpr int SLOT = (WO + 1) * PXS;
+    static constexpr int YCH = 2 * WO * 8, YPT = (YCH + 255) / 256;     // chunks of dY rows y (an image's first step only) and y + 1
+    static constexpr int MCH = 2 * WI * 8, MPT = (MCH + 255) / 256;     // chunks of a step's two output rows
+    static constexpr size_t LDS = (size_t)(3 * SLOT + 4 * WO * PXS) * 2;
+};
+
+template <int WI>
+__global__ __launch_bounds__(256) void dgrad_ring2_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wp, bf16* __restrict__ dx,
+                                                          const bf16* __restrict__ mask_raw, const float* __restrict__ mscale,
+                                                          const float* __restrict__ mshift, float* s_dy, float* s_dyr, int N, int HI, int C,
+                                                          StesDet det) {
+    typedef DgradShape<WI> S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
+    bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [3][SLOT]
+    bf16* stage = ring + 3 * S::SLOT;                                       // [row parity][column parity][WO][PXS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int HO = HI / 2, slice = blockIdx.y, cb = slice * 64;
+    for (int i = tid; i < 3 * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // the right-hand pixels stay zero
+    // taps by (k-step, half) of the parity-class pack of stes_pack_conv3x3g: (1,1) | (1,0),(1,2) | (0,1),(2,1) | (0,0),(0,2) | (2,0),(2,2)
+    const int g = slice * 4 + wave;
+    const r_s16x4 w11 = cr_tap_frag(wp, g, 0, lane), w10 = cr_tap_frag(wp, g, 2, lane), w12 = cr_tap_frag(wp, g, 3, lane);
+    const r_s16x4 w01 = cr_tap_frag(wp, g, 4, lane), w21 = cr_tap_frag(wp, g, 5, lane), w00 = cr_tap_frag(wp, g, 6, lane);
+    const r_s16x4 w02 = cr_tap_frag(wp, g, 7, lane), w20 = cr_tap_frag(wp, g, 8, lane), w22 = cr_tap_frag(wp, g, 9, lane);
+    const int chunk = tid & 7;
+    const bool masked = mask_raw != nullptr;
+    float sc[8], sh[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = masked ? mscale[cb + chunk * 8 + e] : 0.f; sh[e] = masked ? mshift[cb + chunk * 8 + e] : 0.f;
+        ssum[e] = 0.f; ssq[e] = 0.f;
+    }
+    const int ch0 = wave * 16 + 4 * fq;
+    __syncthreads();
+
+    const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int total = nimg * HO;
+    int yn = blockIdx.x, yy = 0;                                            // the step the next dY request is for
+    auto fetch_y = [&](bf16x8 (&dst)[S::YPT]) {
+        if (yn < N) {
+            const bf16* src = dy + ((long)yn * HO + yy) * S::WO * C + cb + chunk * 8;
+#pragma unroll
+            for (int k = 0; k < S::YPT; ++k) {
+                const int i = tid + 256 * k;
+                if (i < S::YCH) {
+                    const int p = i >> 3;                                   // pixel of the strip of rows yy and yy + 1
+                    dst[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (p < S::WO ? yy == 0 : yy + 1 < HO) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)p * C);
+                }
+            }
+        }
+        if (++yy == HO) { yy = 0; yn += gridDim.x; }
+    };
+    int mn = blockIdx.x, my = 0;                                            // the step the next request of raw rows is for
+    auto fetch_m = [&](bf16x8 (&dst)[S::MPT]) {
+        if (masked && mn < N) {
+            const bf16* src = mask_raw + ((long)mn * HI + 2 * my) * WI * C + cb + chunk * 8;
+#pragma unroll
+            for (int k = 0; k < S::MPT; ++k) {
+                const int i = tid + 256 * k;
+                if (i < S::MCH) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
+            }
+        }
+        if (++my == HO) { my = 0; mn += gridDim.x; }
+    };
+    int n = blockIdx.x, y = 0, s0 = 0;                                      // this step; ring slot of dY row y
+    auto step = [&](bf16x8 (&raw)[S::YPT], bf16x8 (&m)[S::MPT]) {
+        if (y == 0) s0 = 0;
+        const int s1 = s0 == 2 ? 0 : s0 + 1;
+        // (a) dY row y + 1 (zeros after the last row) into the slot behind row y's; row y itself on an image's first step
+#pragma unroll
+        for (int k = 0; k < S::YPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::YCH) {
+                const int p = i >> 3, row = p >= S::WO ? 1 : 0, px = p - row * S::WO;
+                if (row == 1 || y == 0) *reinterpret_cast<bf16x8*>(ring + (row ? s1 : s0) * S::SLOT + px * S::PXS + chunk * 8) = raw[k];
+            }
+        }
+        fetch_y(raw);
+        __syncthreads();
+        // (b) output rows 2y and 2y + 1
+        const bf16* rowy = ring + s0 * S::SLOT + ch0;
+        const bf16* rowy1 = ring + s1 * S::SLOT + ch0;
+#pragma unroll
+        for (int f = 0; f < S::CF; ++f) {
+            const int j = 16 * f + fr, jc = min(j, S::WO - 1);
+            const r_s16x4 r0 = *reinterpret_cast<const r_s16x4*>(rowy + jc * S::PXS);
+            const r_s16x4 r1 = *reinterpret_cast<const r_s16x4*>(rowy + (jc + 1) * S::PXS);
+            const r_s16x4 t0 = *reinterpret_cast<const r_s16x4*>(rowy1 + jc * S::PXS);
+            const r_s16x4 t1 = *reinterpret_cast<const r_s16x4*>(rowy1 + (jc + 1) * S::PXS);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 ee = CR_MFMA16(w11, r0, z);
+            f32x4 eo = CR_MFMA16(w10, r1, z);
+            f32x4 oe = CR_MFMA16(w01, t0, z);
+            f32x4 oo = CR_MFMA16(w00, t1, z);
+            eo = CR_MFMA16(w12, r0, eo);
+            oe = CR_MFMA16(w21, r0, oe);
+            oo = CR_MFMA16(w02, t0, oo);
+            oo = CR_MFMA16(w20, r1, oo);
+            oo = CR_MFMA16(w22, r0, oo);
+            if (j < S::WO) {
+                bf16x4 o0, o1, o2, o3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o0[e] = (bf16)ee[e]; o1[e] = (bf16)eo[e]; o2[e] = (bf16)oe[e]; o3[e] = (bf16)oo[e]; }
+                bf16* at = stage + j * S::PXS + ch0;
+                *reinterpret_cast<bf16x4*>(at) = o0;
+                *reinterpret_cast<bf16x4*>(at + S::WO * S::PXS) = o1;
+                *reinterpret_cast<bf16x4*>(at + 2 * S::WO * S::PXS) = o2;
+                *reinterpret_cast<bf16x4*>(at + 3 * S::WO * S::PXS) = o3;
+            }
+        }
+        __syncthreads();
+        // the two rows leave: 2 * WI pixels, contiguous in memory
+        bf16* dst = dx + ((long)n * HI + 2 * y) * WI * C + cb + chunk * 8;
+#pragma unroll
+        for (int k = 0; k < S::MPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::MCH) {
+                const int p = i >> 3, row = p >= WI ? 1 : 0, w = p - row * WI;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + ((row * 2 + (w & 1)) * S::WO + (w >> 1)) * S::PXS + chunk * 8);
+                if (masked) {
+                    const bf16x8 r = m[k];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float rf = (float)r[e];
+                        if (!(rf * sc[e] + sh[e] > 0.f)) v[e] = (bf16)0.f;
+                        const float fv = (float)v[e];
+                        ssum[e] += fv; ssq[e] += fv * rf;
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(dst + (long)p * C) = v;
+            }
+        }
+        fetch_m(m);
+        s0 = s1;
+        if (++y == HO) { y = 0; n += gridDim.x; }
+    };
+    bf16x8 rawA[S::YPT], rawB[S::YPT], mA[S::MPT], mB[S::MPT];
+    fetch_y(rawA);
+    fetch_m(mA);
+    fetch_y(rawB);
+    fetch_m(mB);
+#pragma unroll 1
+    for (int s = 0; s < total; s += 2) {
+        step(rawA, mA);
+        if (s + 1 < total) step(rawB, mB);
+    }
+    if (masked) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                                      // lanes with the same eight channels
+            ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+            ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(ring);                        // [4 waves][2][64]
+        __syncthreads();
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[wave * 128 + lane * 8 + e] = ssum[e]; red[wave * 128 + 64 + lane * 8 + e] = ssq[e]; }
+        }
+        __syncthreads();
+        det_enter(det);
+        if (wave == 0) {                                                    // one 64-lane atomic per workgroup and array, as in the forward
+            atomicAdd(s_dy + cb + lane, (red[lane] + red[128 + lane]) + (red[256 + lane] + red[384 + lane]));
+            atomicAdd(s_dyr + cb + lane, (red[64 + lane] + red[192 + lane]) + (red[320 + lane] + red[448 + lane]));
+        }
+        det_leave(det);
+    }
+}
+
+template <int WI>
+int dgrad_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx, const uint16_t* mask_raw, const float* mscale, const float* mshift,
+                 float* s_dy, float* s_dyr, int N, int Hi, int C, void* stream) {
+    typedef DgradShape<WI> S;
+    static_assert(S::LDS >= 4 * 128 * sizeof(float) && 3 * S::SLOT * 2 >= 4 * 128 * sizeof(float), "the statistics reduction reuses the ring");
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_ring2_kernel<WI>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    STES_CHECK(big_lds, STES_ERR_UNSUPPORTED, "stes_conv3x3g_dgrad: cannot raise the dynamic LDS limit");
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dgrad_ring2_kernel<WI>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = per_cu * (cus < 1 ? 256 : cus);
+    }
+    const int slices = C / 64;
+    int gx = resident / slices;
+    if (gx < 1) gx = 1;
+    if (gx > N) gx = N;
+    hipLaunchKernelGGL((dgrad_ring2_kernel<WI>), dim3(gx, slices), dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)dy, (const bf16*)wp, (bf16*)dx,
+                       (const bf16*)mask_raw, mscale, mshift, s_dy, s_dyr, N, Hi, C, mask_raw ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+template <int WI>
+int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
+                float* col_sumsq, int N, int Hi, int C, void* stream) {
+    typedef RingShape<WI> S;
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring2_kernel<WI>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    STES_CHECK(big_lds, STES_ERR_UNSUPPORTED, "stes_conv3x3g: cannot raise the dynamic LDS limit");
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring2_kernel<WI>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = per_cu * (cus < 1 ? 256 : cus);
+    }
+    const int slices = C / 64;
+    int gx = resident / slices;
+    if (gx < 1) gx = 1;
+    if (gx > N) gx = N;
+    const dim3 grid(gx, slices);
+    hipLaunchKernelGGL((conv_ring2_kernel<WI>), grid, dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp, (bf16*)out, scale,
+                       shift, col_sum, col_sumsq, N, Hi, C, col_sum ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
+}  // namespace
+
+bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
+    static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
+    return on && mode == 0 && stride == 2 && !pooled && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
+}
+
+bool stes_dgrad_ring_takes(int mode, int stride, int Hi, int Wi) {
+    static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
+    return on && mode == 1 && stride == 2 && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
+}
+
+int stes_dgrad_ring_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx, const uint16_t* mask_raw, const float* mscale,
+                           const float* mshift, float* s_dy, float* s_dyr, int N, int Hi, int Wi, int C, void* stream) {
+    if (Wi == 112) return dgrad_launch<112>(dy, wp, dx, mask_raw, mscale, mshift, s_dy, s_dyr, N, Hi, C, stream);
+    if (Wi == 56) return dgrad_launch<56>(dy, wp, dx, mask_raw, mscale, mshift, s_dy, s_dyr, N, Hi, C, stream);
+    if (Wi == 28) return dgrad_launch<28>(dy, wp, dx, mask_raw, mscale, mshift, s_dy, s_dyr, N, Hi, C, stream);
+    if (Wi == 14) return dgrad_launch<14>(dy, wp, dx, mask_raw, mscale, mshift, s_dy, s_dyr, N, Hi, C, stream);
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_dgrad_ring: map width");
+}
+
+int stes_conv_ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
+                          float* col_sumsq, int N, int Hi, int Wi, int C, void* stream) {
+    if (Wi == 112) return ring_launch<112>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
+    if (Wi == 56) return ring_launch<56>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
+    if (Wi == 28) return ring_launch<28>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
+    if (Wi == 14) return ring_launch<14>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_conv_ring: map width");
+}

@@ -239,6 +239,11 @@ def _conv_bytes(a):
     return 2 * c * n * (hi * wi + ho * wo)
 
 
+def _ring2(a):
+    n, hi, wi, ho, wo, stride, c = a[-7:]
+    return stride == 2 and hi % 2 == 0 and wi in (112, 56, 28, 14)
+
+
 def _stem_bytes(a):
     e_slice, e_slice_n, b, t, tv, cin, h, w = a[11:19]
     pix = b * t * ((h + 1) // 2) * ((w + 1) // 2)
@@ -271,11 +276,13 @@ _KERNEL_OF = {
     "stes_clip_gate_bwd": (lambda a: "clip_gate_bwd_reduce_kernel" if a[5] is not None else "clip_gate_bwd_apply_kernel", None),
     # (names as a kernel trace prints them, for the shapes of the named configuration: all of them fit the LDS-window kernels)
     # (stride-1 maps of at most 14 columns go to the column-strip kernel: the rule of stes_conv_strip_takes)
+    # (stride-2 maps 112, 56, 28 or 14 wide of even height go to the row-ring kernels: the rule of stes_conv_ring_takes)
     "stes_conv3x3g_fwd": (lambda a: "conv3x3g_strip_kernel<true, 1>" if a[-2] == 1 and a[-5] <= 14 else
-                          "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
+                          "conv_ring2_kernel<%d>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
     "stes_conv3x3g_fwd_pool": (lambda a: "conv3x3g_strip_kernel<true, 3>" if a[-2] == 1 and a[-5] <= 14 else
                                "conv3x3g_rows_kernel<%d, false, true>" % a[-2], _conv_bytes),
     "stes_conv3x3g_dgrad": (lambda a: "conv3x3g_rows_kernel<1, true>" if a[-2] == 1 else
+                            "dgrad_ring2_kernel<%d>" % a[-5] if _ring2(a) else
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
     "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),

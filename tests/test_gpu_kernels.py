@@ -51,7 +51,12 @@ def close(a, b, rtol=1e-2, atol=1e-2):
                                                (1, 7, 7, 64, 1500), (1, 4, 4, 320, 900), (1, 14, 9, 64, 333), (1, 2, 2, 128, 2000),
                                                # several images per workgroup of the LDS-window kernel on maps of fewer than 8 output pixels
                                                # (the pooled sums of the four waves need more staging space than such a map's pixels)
-                                               (2, 4, 4, 128, 600), (2, 3, 3, 64, 1100), (2, 4, 6, 64, 1100)])
+                                               (2, 4, 4, 128, 600), (2, 3, 3, 64, 1100), (2, 4, 6, 64, 1100),
+                                               # the stride-2 row-ring kernels (maps 112, 56, 28 and 14 wide, even height): every
+                                               # width, heights of one and a few output rows, more images than resident workgroups
+                                               # (a workgroup's images follow one another without a pause in its row requests)
+                                               (2, 112, 112, 64, 5), (2, 20, 28, 64, 3), (2, 6, 14, 64, 9), (2, 2, 56, 64, 2), (2, 2, 14, 128, 5),
+                                               (2, 28, 28, 64, 1300), (2, 14, 14, 192, 2100)])
 def test_conv3x3g(stride, H, W, C, N):
     from spot_amd import lib
     g = torch.Generator().manual_seed(3)
