@@ -1106,6 +1106,8 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     STES_CHECK(stride == 1 || stride == 2, STES_ERR_ARG, "stes_conv3x3g: stride must be 1 or 2");
     STES_CHECK(Ho == (Hi + 2 - 3) / stride + 1 && Wo == (Wi + 2 - 3) / stride + 1, STES_ERR_ARG, "stes_conv3x3g: output size does not match");
     STES_CHECK((scale == nullptr) == (shift == nullptr) && (col_sum == nullptr) == (col_sumsq == nullptr), STES_ERR_ARG, "stes_conv3x3g: paired pointers");
+    if (stes_conv_ring1_takes(mode, stride, Wi, pool_out != nullptr))
+        return stes_conv_ring1_launch(mode, src, wp, dst, mask_raw, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
     if (stes_conv_strip_takes(mode, stride, Wi))         // 14 x 14 and 7 x 7 maps, forward: operands straight from memory, no LDS window
         return stes_conv_strip_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream, pool_scale, pool_shift, pool_out,
                                       pool_norm);

@@ -392,6 +392,246 @@ int dgrad_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx, const uin
     return STES_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- stride 1
+// The identity blocks' convolution on the 7-wide maps of the last stage, forward and input gradient in one kernel: the input gradient of a
+// stride-1 convolution is the same convolution with the taps mirrored (and the channel roles exchanged, which the weight pack
+// for the gradient already holds).  R output rows per step from a ring of R + 2 input rows (slots: a power of two); a 7-wide
+// map puts two output rows into one 16-lane fragment.  Forward: BatchNorm + ReLU on the way in, sum and sum of squares of the
+// output on the way out.  Gradient: nothing on the way in; the ReLU mask and s_dy += dX, s_dyr += dX * raw on the way out.
+template <int W, int R>
+struct Ring1Shape {
+    static constexpr bool PACK = W <= 8;                    // two output rows per fragment
+    static constexpr int CF = (W + 15) / 16;
+    static constexpr int NS = R + 2 <= 4 ? 4 : R + 2 <= 8 ? 8 : 16;          // ring slots; input row r lives in slot (r + 1) & (NS - 1)
+    static_assert(R % 2 == 0 && R + 2 <= NS, "a step's R + 2 input rows are in the ring together");
+    static constexpr int PXS = 64 + 8;
+    static constexpr int SLOT = (W + 2) * PXS;
+    static constexpr int ICH = (R + 1) * W * 8, IPT = (ICH + 255) / 256;      // chunks of input rows R t (an image's first step only) .. R t + R
+    static constexpr int OCH = R * W * 8, OPT = (OCH + 255) / 256;            // chunks of a step's output rows
+    static constexpr size_t LDS = (size_t)(NS * SLOT + R * W * PXS) * 2;
+};
+
+template <int W, int R, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict__ in, const bf16* __restrict__ wp, bf16* __restrict__ out,
+                                                         const bf16* __restrict__ mask_raw, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* sum_a, float* sum_b, int N, int H, int C,
+                                                         StesDet det) {
+    typedef Ring1Shape<W, R> S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
+    bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [NS][SLOT]
+    bf16* stage = ring + S::NS * S::SLOT;                                   // [R][W][PXS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int slice = blockIdx.y, cb = slice * 64, HT = (H + R - 1) / R;    // steps per image
+    for (int i = tid; i < S::NS * S::SLOT / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;     // the border pixels stay zero
+    r_s16x4 wA[3][3];                                                       // wA[a][b] multiplies input row h + a - 1, column w + b - 1
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wA[a][b] = cr_tap_frag(wp, slice * 4 + wave, DGRAD ? 8 - (a * 3 + b) : a * 3 + b, lane);
+    const int chunk = tid & 7;
+    const bool affine = scale != nullptr;                                   // forward: the input transform; gradient: the mask's
+    const bool masked = DGRAD && mask_raw != nullptr;
+    const bool stats = sum_a != nullptr;
+    float sc[8], sh[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = affine ? scale[cb + chunk * 8 + e] : 1.f; sh[e] = affine ? shift[cb + chunk * 8 + e] : 0.f;
+        ssum[e] = 0.f; ssq[e] = 0.f;
+    }
+    const int ch0 = wave * 16 + 4 * fq;
+    __syncthreads();
+
+    const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int total = nimg * HT;
+    int in_n = blockIdx.x, in_t = 0;                                        // the step the next request of input rows is for
+    auto fetch_in = [&](bf16x8 (&dst)[S::IPT]) {
+        if (in_n < N) {
+            const bf16* src = in + ((long)in_n * H + R * in_t) * W * C + cb + chunk * 8;
+#pragma unroll
+            for (int k = 0; k < S::IPT; ++k) {
+                const int i = tid + 256 * k;
+                if (i < S::ICH) {
+                    const int p = i >> 3, c = p / W;                        // chunk row c: input row R t + c
+                    dst[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (c == 0 ? in_t == 0 : R * in_t + c < H) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)p * C);
+                }
+            }
+        }
+        if (++in_t == HT) { in_t = 0; in_n += gridDim.x; }
+    };
+    int m_n = blockIdx.x, m_t = 0;                                          // the step the next request of raw rows under the mask is for
+    auto fetch_m = [&](bf16x8 (&dst)[S::OPT]) {
+        if (masked && m_n < N) {
+            const bf16* src = mask_raw + ((long)m_n * H + R * m_t) * W * C + cb + chunk * 8;
+            const int pix = min(R, H - R * m_t) * W;
+#pragma unroll
+            for (int k = 0; k < S::OPT; ++k) {
+                const int i = tid + 256 * k;
+                if (i < S::OCH && (i >> 3) < pix) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
+            }
+        }
+        if (++m_t == HT) { m_t = 0; m_n += gridDim.x; }
+    };
+    int n = blockIdx.x, t = 0;
+    auto step = [&](bf16x8 (&raw)[S::IPT], bf16x8 (&m)[S::OPT]) {
+        const int h0 = R * t;                                               // first output row of the step
+        if (t == 0) {                                                       // row -1 of an image: zeros
+            for (int i = tid; i < W * 32; i += 256) reinterpret_cast<unsigned*>(ring + ((i >> 5) + 1) * S::PXS)[i & 31] = 0u;
+        }
+        // (a) input rows h0 + 1 .. h0 + R (zeros below the image) into the slots of rows no longer needed; row h0 on a first step
+#pragma unroll
+        for (int k = 0; k < S::IPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::ICH) {
+                const int p = i >> 3, c = p / W, px = p - c * W;
+                if (c > 0 || t == 0) {
+                    bf16x8 v = raw[k];
+                    if (!DGRAD && affine && h0 + c < H) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f);
+                    }
+                    *reinterpret_cast<bf16x8*>(ring + ((h0 + c + 1) & (S::NS - 1)) * S::SLOT + (px + 1) * S::PXS + chunk * 8) = v;
+                }
+            }
+        }
+        fetch_in(raw);
+        __syncthreads();
+        // (b) output rows h0 .. h0 + R - 1: row h of the output reads input rows h - 1, h, h + 1 = slots (h + a) & (NS - 1)
+        if constexpr (S::PACK) {
+#pragma unroll
+            for (int u = 0; u < R / 2; ++u) {
+                const int rr = 2 * u + (fr >> 3), col = min(fr & 7, W - 1);
+                if (h0 + 2 * u < H) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const bf16* row = ring + ((h0 + rr + a) & (S::NS - 1)) * S::SLOT + col * S::PXS + ch0;
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) acc = CR_MFMA16(wA[a][b], *reinterpret_cast<const r_s16x4*>(row + b * S::PXS), acc);
+                    }
+                    if ((fr & 7) < W) {
+                        bf16x4 ob;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[e];
+                        *reinterpret_cast<bf16x4*>(stage + (rr * W + col) * S::PXS + ch0) = ob;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                if (h0 + rr < H) {
+                    f32x4 acc[S::CF];
+#pragma unroll
+                    for (int f = 0; f < S::CF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const bf16* row = ring + ((h0 + rr + a) & (S::NS - 1)) * S::SLOT + ch0;
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+#pragma unroll
+                            for (int f = 0; f < S::CF; ++f) {
+                                const int col = min(16 * f + fr, W - 1);
+                                acc[f] = CR_MFMA16(wA[a][b], *reinterpret_cast<const r_s16x4*>(row + (col + b) * S::PXS), acc[f]);
+                            }
+                    }
+#pragma unroll
+                    for (int f = 0; f < S::CF; ++f) {
+                        const int col = 16 * f + fr;
+                        if (col < W) {
+                            bf16x4 ob;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[f][e];
+                            *reinterpret_cast<bf16x4*>(stage + (rr * W + col) * S::PXS + ch0) = ob;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // the rows leave as 16-byte chunks, contiguous in memory
+        bf16* dst = out + ((long)n * H + h0) * W * C + cb + chunk * 8;
+        const int pix = min(R, H - h0) * W;
+#pragma unroll
+        for (int k = 0; k < S::OPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::OCH && (i >> 3) < pix) {
+                const int p = i >> 3;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + p * S::PXS + chunk * 8);
+                if (masked) {
+                    const bf16x8 r = m[k];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float rf = (float)r[e];
+                        if (!(rf * sc[e] + sh[e] > 0.f)) v[e] = (bf16)0.f;
+                        const float fv = (float)v[e];
+                        ssum[e] += fv; ssq[e] += fv * rf;
+                    }
+                } else if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float fv = (float)v[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+                }
+                *reinterpret_cast<bf16x8*>(dst + (long)p * C) = v;
+            }
+        }
+        fetch_m(m);
+        if (++t == HT) { t = 0; n += gridDim.x; }
+    };
+    bf16x8 rawA[S::IPT], rawB[S::IPT], mA[S::OPT], mB[S::OPT];
+    fetch_in(rawA);
+    fetch_m(mA);
+    fetch_in(rawB);
+    fetch_m(mB);
+#pragma unroll 1
+    for (int s = 0; s < total; s += 2) {
+        step(rawA, mA);
+        if (s + 1 < total) step(rawB, mB);
+    }
+    if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                                      // lanes with the same eight channels
+            ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+            ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(ring);                        // [4 waves][2][64]
+        __syncthreads();
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[wave * 128 + lane * 8 + e] = ssum[e]; red[wave * 128 + 64 + lane * 8 + e] = ssq[e]; }
+        }
+        __syncthreads();
+        det_enter(det);
+        if (wave == 0) {
+            atomicAdd(sum_a + cb + lane, (red[lane] + red[128 + lane]) + (red[256 + lane] + red[384 + lane]));
+            atomicAdd(sum_b + cb + lane, (red[64 + lane] + red[192 + lane]) + (red[320 + lane] + red[448 + lane]));
+        }
+        det_leave(det);
+    }
+}
+
+template <int W, int R, bool DGRAD>
+int ring1_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale, const float* shift,
+                 float* sum_a, float* sum_b, int N, int H, int C, void* stream) {
+    typedef Ring1Shape<W, R> S;
+    static_assert(S::NS * S::SLOT * 2 >= 4 * 128 * sizeof(float), "the statistics reduction reuses the ring");
+    static_assert(S::LDS <= 64 * 1024, "within the default dynamic LDS limit");
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring1_kernel<W, R, DGRAD>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = per_cu * (cus < 1 ? 256 : cus);
+    }
+    const int slices = C / 64;
+    int gx = resident / slices;
+    if (gx < 1) gx = 1;
+    if (gx > N) gx = N;
+    hipLaunchKernelGGL((conv_ring1_kernel<W, R, DGRAD>), dim3(gx, slices), dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp,
+                       (bf16*)out, (const bf16*)mask_raw, scale, shift, sum_a, sum_b, N, H, C, sum_a ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
 template <int WI>
 int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
                 float* col_sumsq, int N, int Hi, int C, void* stream) {
@@ -422,6 +662,24 @@ int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const flo
 bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
     return on && mode == 0 && stride == 2 && !pooled && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
+}
+
+bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {
+    static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
+    // (measured on 1,024 images against the window and column-strip kernels: 7 x 7 x 768 forward 49 vs 67 us, masked gradient 62 vs
+    // 96; 14 x 14 x 320 75 vs 73 and 132 vs 117, 28 x 28 x 128 142 vs 144 and 185 vs 175 with 2 to 8 rows per step -- at stride 1
+    // the window kernels read an input pixel from LDS no more often than this one, so only the smallest map is taken)
+    return on && stride == 1 && !pooled && (mode == 0 || mode == 1) && Wi == 7;
+}
+
+int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
+                           const float* shift, float* sum_a, float* sum_b, int N, int H, int W, int C, void* stream) {
+#define RING1(WW, RR)                                                                                                                  \
+    if (W == WW) return mode == 0 ? ring1_launch<WW, RR, false>(in, wp, out, nullptr, scale, shift, sum_a, sum_b, N, H, C, stream)     \
+                                  : ring1_launch<WW, RR, true>(in, wp, out, mask_raw, scale, shift, sum_a, sum_b, N, H, C, stream)
+    RING1(7, 8);
+#undef RING1
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_conv_ring1: map width");
 }
 
 bool stes_dgrad_ring_takes(int mode, int stride, int Hi, int Wi) {

@@ -56,7 +56,10 @@ def close(a, b, rtol=1e-2, atol=1e-2):
                                                # width, heights of one and a few output rows, more images than resident workgroups
                                                # (a workgroup's images follow one another without a pause in its row requests)
                                                (2, 112, 112, 64, 5), (2, 20, 28, 64, 3), (2, 6, 14, 64, 9), (2, 2, 56, 64, 2), (2, 2, 14, 128, 5),
-                                               (2, 28, 28, 64, 1300), (2, 14, 14, 192, 2100)])
+                                               (2, 28, 28, 64, 1300), (2, 14, 14, 192, 2100),
+                                               # the stride-1 row-ring kernel (7 wide, eight rows a step): fewer rows than a step, two
+                                               # steps, a last step of one row
+                                               (1, 5, 7, 64, 40), (1, 16, 7, 128, 300), (1, 9, 7, 64, 3)])
 def test_conv3x3g(stride, H, W, C, N):
     from spot_amd import lib
     g = torch.Generator().manual_seed(3)
@@ -100,7 +103,12 @@ def test_conv3x3g(stride, H, W, C, N):
         pooled_b = torch.empty(1, C, dtype=BF, device="cuda")
         lib.call("stes_conv3x3g_fwd_pool", lib.ptr(xd), lib.ptr(wp_f), lib.ptr(torch.empty_like(out)), *args, lib.ptr(pooled_b), 1, H, W, Ho, Wo, stride, C)
         torch.cuda.synchronize()
-        assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+        if (stride == 1 and W == 7) or (stride == 2 and H % 2 == 0 and W in (112, 56, 28, 14)):
+            # these shapes' plain forward is the row-ring kernel (K = 16 MFMAs, one tap each), the pooled forward the window
+            # kernel (K = 32, two taps each): the fp32 sums are taken in another order
+            close(out2.float(), out.float(), 1e-2, 2e-2)
+        else:
+            assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
         close(pooled.float(), want.float(), 1e-2, 1e-3)
         assert torch.equal(pooled_b[0].view(torch.int16), pooled[0].view(torch.int16))
     # dgrad
