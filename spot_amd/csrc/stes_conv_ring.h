@@ -15,7 +15,7 @@ int stes_dgrad_ring_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx,
                            const float* mshift, float* s_dy, float* s_dyr, int N, int Hi, int Wi, int C, void* stream);
 
 // Stride 1, forward (mode 0: in -> out with the input transform and the output's sums) and input gradient (mode 1: in = dY,
-// out = dX, with the mask and the BatchNorm backward sums when mask_raw is given), maps 7 wide of any height.
+// out = dX, with the mask and the BatchNorm backward sums when mask_raw is given), maps 28, 14 or 7 wide of any height.
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled);
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
                            const float* shift, float* sum_a, float* sum_b, int N, int H, int W, int C, void* stream);

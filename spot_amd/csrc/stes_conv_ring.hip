@@ -75,26 +75,30 @@ __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict_
     const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
     const int total = nimg * HO;
     int fn = blockIdx.x, fro = 0;                                           // the step the next request is for
+    // Every request is made by every thread on every step (threads without a chunk and steps past the workgroup's last
+    // repeat a valid address and drop the result): the wait in front of a buffer's use is then counted in instructions --
+    // "all but the other buffer's requests" -- where a request under a condition would make it "everything outstanding",
+    // the rows asked for a moment ago included.
     auto fetch = [&](bf16x8 (&dst)[S::CPT]) {
-        if (fn < N) {
-            const bf16* src = in + ((long)fn * HI + 2 * fro) * WI * C + cb + chunk * 8;
+        const bf16* src = in + ((long)min(fn, N - 1) * HI + 2 * fro) * WI * C + cb + chunk * 8;
 #pragma unroll
-            for (int k = 0; k < S::CPT; ++k) {
-                const int i = tid + 256 * k;                                // chunk i: pixel i >> 3 of the two-row strip
-                if (i < S::CHUNKS) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
-            }
+        for (int k = 0; k < S::CPT; ++k) {
+            const int i = k < S::CHUNKS / 256 ? tid + 256 * k : min(tid + 256 * k, S::CHUNKS - 1);        // chunk i: pixel i >> 3 of the two-row strip
+            dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
         }
         if (++fro == HO) { fro = 0; fn += gridDim.x; }
     };
-    int n = blockIdx.x, ro = 0, pn = 0, pro = -1;                           // this step, the step before
-    auto step = [&](bf16x8 (&raw)[S::CPT]) {
-        if (pro >= 0) {                                                     // the staged output row of the step before leaves as whole chunks
+    int n = blockIdx.x, ro = 0, pn = 0, pro = -1;                           // this step, the step before (-1: nothing staged)
+    auto flush = [&]() {                                                    // the staged output row of the step before leaves as whole chunks
+        if (pro >= 0) {
             bf16* dst = out + (((long)pn * HO + pro) * S::WO) * C + cb;
             for (int idx = tid; idx < S::WO * 8; idx += 256) {
                 const int co = idx >> 3, c0 = (idx & 7) * 8;
                 *reinterpret_cast<bf16x8*>(dst + (long)co * C + c0) = *reinterpret_cast<const bf16x8*>(stage + co * S::SPX + c0);
             }
         }
+    };
+    auto step = [&](bf16x8 (&raw)[S::CPT], bool live) {
         if (ro == 0) {                                                      // row -1 of an image: zeros (slot 0 holds rows 3, 7, .. later)
             for (int i = tid; i < WI * 32; i += 256) reinterpret_cast<unsigned*>(ring + ((i >> 5) + 1) * S::PXS)[i & 31] = 0u;
         }
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict_
             }
         }
         fetch(raw);                                                         // the rows of two steps on
+        flush();
         __syncthreads();
         // (b) output row ro: source rows 2ro-1, 2ro, 2ro+1 = slots (2ro + a) & 3
         f32x4 acc[S::CF];
@@ -141,29 +146,25 @@ __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[f][e];
                 *reinterpret_cast<bf16x4*>(stage + co * S::SPX + ch0) = ob;
+                if (live) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float fv = (float)ob[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+                    for (int e = 0; e < 4; ++e) { const float fv = (float)ob[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+                }
             }
         }
         __syncthreads();
-        pn = n; pro = ro;
+        pn = n; pro = live ? ro : -1;
         if (++ro == HO) { ro = 0; n += gridDim.x; }
     };
     bf16x8 rawA[S::CPT], rawB[S::CPT];
     fetch(rawA);
     fetch(rawB);
 #pragma unroll 1
-    for (int s = 0; s < total; s += 2) {
-        step(rawA);
-        if (s + 1 < total) step(rawB);
+    for (int s = 0; s < total; s += 2) {                                    // (an odd count ends with a step whose results are dropped)
+        step(rawA, true);
+        step(rawB, s + 1 < total);
     }
-    if (pro >= 0) {
-        bf16* dst = out + (((long)pn * HO + pro) * S::WO) * C + cb;
-        for (int idx = tid; idx < S::WO * 8; idx += 256) {
-            const int co = idx >> 3, c0 = (idx & 7) * 8;
-            *reinterpret_cast<bf16x8*>(dst + (long)co * C + c0) = *reinterpret_cast<const bf16x8*>(stage + co * S::SPX + c0);
-        }
-    }
+    flush();
     if (col_sum) {
         // one 64-lane atomic per workgroup and array (a lane per channel): the workgroups end together and their additions to
         // the same 64 addresses queue up at the L2, so every instruction less is time off the kernel's tail
@@ -393,7 +394,7 @@ int dgrad_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx, const uin
 }
 
 // ---------------------------------------------------------------------------------------------- stride 1
-// The identity blocks' convolution on the 7-wide maps of the last stage, forward and input gradient in one kernel: the input gradient of a
+// The identity blocks' convolution (maps 28, 14 and 7 wide), forward and input gradient in one kernel: the input gradient of a
 // stride-1 convolution is the same convolution with the taps mirrored (and the channel roles exchanged, which the weight pack
 // for the gradient already holds).  R output rows per step from a ring of R + 2 input rows (slots: a power of two); a 7-wide
 // map puts two output rows into one 16-lane fragment.  Forward: BatchNorm + ReLU on the way in, sum and sum of squares of the
@@ -444,36 +445,34 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
     const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
     const int total = nimg * HT;
     int in_n = blockIdx.x, in_t = 0;                                        // the step the next request of input rows is for
+    // (every request is made by every thread on every step and unwanted results are dropped, so that the waits are counted
+    // in instructions: see the stride-2 forward kernel)
     auto fetch_in = [&](bf16x8 (&dst)[S::IPT]) {
-        if (in_n < N) {
-            const bf16* src = in + ((long)in_n * H + R * in_t) * W * C + cb + chunk * 8;
+        const bf16* src = in + ((long)min(in_n, N - 1) * H + R * in_t) * W * C + cb + chunk * 8;
+        const int last = (H - R * in_t) * W - 1;                            // last pixel from row R t on inside the image
 #pragma unroll
-            for (int k = 0; k < S::IPT; ++k) {
-                const int i = tid + 256 * k;
-                if (i < S::ICH) {
-                    const int p = i >> 3, c = p / W;                        // chunk row c: input row R t + c
-                    dst[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    if (c == 0 ? in_t == 0 : R * in_t + c < H) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)p * C);
-                }
-            }
+        for (int k = 0; k < S::IPT; ++k) {
+            const int i = k < S::ICH / 256 ? tid + 256 * k : min(tid + 256 * k, S::ICH - 1);
+            const int p = i >> 3, c = p / W;                                // chunk row c: input row R t + c
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)min(p, last) * C);
+            dst[k] = (c == 0 ? in_t == 0 : R * in_t + c < H) ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
         if (++in_t == HT) { in_t = 0; in_n += gridDim.x; }
     };
     int m_n = blockIdx.x, m_t = 0;                                          // the step the next request of raw rows under the mask is for
+    const bf16* mbase = masked ? mask_raw : in;                             // (without a mask: any readable map of the size; dropped)
     auto fetch_m = [&](bf16x8 (&dst)[S::OPT]) {
-        if (masked && m_n < N) {
-            const bf16* src = mask_raw + ((long)m_n * H + R * m_t) * W * C + cb + chunk * 8;
-            const int pix = min(R, H - R * m_t) * W;
+        const bf16* src = mbase + ((long)min(m_n, N - 1) * H + R * m_t) * W * C + cb + chunk * 8;
+        const int last = min(R, H - R * m_t) * W - 1;
 #pragma unroll
-            for (int k = 0; k < S::OPT; ++k) {
-                const int i = tid + 256 * k;
-                if (i < S::OCH && (i >> 3) < pix) dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)(i >> 3) * C);
-            }
+        for (int k = 0; k < S::OPT; ++k) {
+            const int i = k < S::OCH / 256 ? tid + 256 * k : min(tid + 256 * k, S::OCH - 1);
+            dst[k] = *reinterpret_cast<const bf16x8*>(src + (long)min(i >> 3, last) * C);
         }
         if (++m_t == HT) { m_t = 0; m_n += gridDim.x; }
     };
     int n = blockIdx.x, t = 0;
-    auto step = [&](bf16x8 (&raw)[S::IPT], bf16x8 (&m)[S::OPT]) {
+    auto step = [&](bf16x8 (&raw)[S::IPT], bf16x8 (&m)[S::OPT], bool live) {
         const int h0 = R * t;                                               // first output row of the step
         if (t == 0) {                                                       // row -1 of an image: zeros
             for (int i = tid; i < W * 32; i += 256) reinterpret_cast<unsigned*>(ring + ((i >> 5) + 1) * S::PXS)[i & 31] = 0u;
@@ -551,7 +550,7 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
         __syncthreads();
         // the rows leave as 16-byte chunks, contiguous in memory
         bf16* dst = out + ((long)n * H + h0) * W * C + cb + chunk * 8;
-        const int pix = min(R, H - h0) * W;
+        const int pix = live ? min(R, H - h0) * W : 0;
 #pragma unroll
         for (int k = 0; k < S::OPT; ++k) {
             const int i = tid + 256 * k;
@@ -583,9 +582,9 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
     fetch_in(rawB);
     fetch_m(mB);
 #pragma unroll 1
-    for (int s = 0; s < total; s += 2) {
-        step(rawA, mA);
-        if (s + 1 < total) step(rawB, mB);
+    for (int s = 0; s < total; s += 2) {                                    // (an odd count ends with a step whose results are dropped)
+        step(rawA, mA, true);
+        step(rawB, mB, s + 1 < total);
     }
     if (stats) {
 #pragma unroll
@@ -666,10 +665,11 @@ bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
 
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
-    // (measured on 1,024 images against the window and column-strip kernels: 7 x 7 x 768 forward 49 vs 67 us, masked gradient 62 vs
-    // 96; 14 x 14 x 320 75 vs 73 and 132 vs 117, 28 x 28 x 128 142 vs 144 and 185 vs 175 with 2 to 8 rows per step -- at stride 1
-    // the window kernels read an input pixel from LDS no more often than this one, so only the smallest map is taken)
-    return on && stride == 1 && !pooled && (mode == 0 || mode == 1) && Wi == 7;
+    // (measured on 1,024 images against the window and column-strip kernels, forward / masked gradient: 7 x 7 x 768 48 vs 67 us and
+    // 51 vs 96; 28 x 28 x 128 107 vs 144 and 139 vs 175; 14 x 14 x 320 74 vs 73 and 93 vs 117 -- the 14-wide forward stays with the
+    // column-strip kernel.  With a request under a condition anywhere in the step all of these were slower than the kernels they
+    // replace: the waits then cover the rows asked for a moment ago.)
+    return on && stride == 1 && !pooled && (Wi == 7 || Wi == 28 || (Wi == 14 && mode == 1)) && (mode == 0 || mode == 1);
 }
 
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
@@ -678,6 +678,8 @@ int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uin
     if (W == WW) return mode == 0 ? ring1_launch<WW, RR, false>(in, wp, out, nullptr, scale, shift, sum_a, sum_b, N, H, C, stream)     \
                                   : ring1_launch<WW, RR, true>(in, wp, out, mask_raw, scale, shift, sum_a, sum_b, N, H, C, stream)
     RING1(7, 8);
+    RING1(14, 4);
+    RING1(28, 2);
 #undef RING1
     return stes_set_error(STES_ERR_UNSUPPORTED, "stes_conv_ring1: map width");
 }

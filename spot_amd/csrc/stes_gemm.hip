@@ -551,6 +551,167 @@ __global__ __launch_bounds__(256) void gemm_small2_kernel(const stes_gemm2_args 
     }
 }
 
+// The same pair of products with every operand brought into LDS first.  The kernel above walks its operands in dependent
+// rounds of loads (the k-batches of a column fragment, then the fragments of the second product: seven memory round trips
+// for the stage-3 shapes), and a round trip is what the pair costs: 15 us alone, 40 us beside the weight-gradient stream.
+// Here the 16 rows of A, W1 and W2 (up to 128 KiB together) are requested at once -- 512 threads, at most 16 chunks of 16
+// bytes each, all in flight together, with the bias and mask values of the epilogues behind them -- and land in LDS rows
+// padded by 16 bytes; both products then read MFMA operands from LDS.  One round trip.  Sums are taken in the order of the
+// kernel above (even and odd k-steps of the first product in two accumulators), so both forms give the same bits.
+constexpr int S2_THREADS = 512, S2_MAXC = 16;
+struct Small2Lds {
+    int sa, sw2;                    // LDS row strides (elements) of A / W1 rows and of W2 / H rows
+    int n1r, n2r;                   // W1 and W2 rows rounded up to whole fragments
+    int c_a, c_w1, c_all;           // chunk counts: A, A + W1, all
+    FastDiv fd_kc1, fd_kc2;         // chunks per row of A / W1 and of W2
+};
+
+__global__ __launch_bounds__(S2_THREADS) void gemm_small2_lds_kernel(const stes_gemm2_args p, const Small2Lds g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2_smem[];
+    bf16* As = reinterpret_cast<bf16*>(s2_smem);                   // [16][sa]
+    bf16* W1s = As + 16 * g.sa;                                    // [n1r][sa]
+    bf16* W2s = W1s + g.n1r * g.sa;                                // [n2r][sw2]
+    bf16* Hs = W2s + g.n2r * g.sw2;                                // [16][sw2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long m0 = (long)blockIdx.x * 16, m = m0 + fr;
+    const bool row_ok = m < p.M;
+    // ---- every operand chunk of the workgroup, requested together
+    bf16x8 regs[S2_MAXC];
+    int at[S2_MAXC];                                               // LDS element offset, -1: no chunk
+#pragma unroll
+    for (int k = 0; k < S2_MAXC; ++k) {
+        const int i = tid + k * S2_THREADS;
+        at[k] = -1;
+        if (i < g.c_all) {
+            uint32_t r, c;
+            if (i < g.c_a) {
+                fdivmod((uint32_t)i, g.fd_kc1, r, c);
+                if (m0 + r < p.M) { regs[k] = *reinterpret_cast<const bf16x8*>((const bf16*)p.A + (m0 + r) * p.lda + c * 8); at[k] = (int)(r * g.sa + c * 8); }
+            } else if (i < g.c_w1) {
+                fdivmod((uint32_t)(i - g.c_a), g.fd_kc1, r, c);
+                regs[k] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W1 + (long)r * p.ldw1 + c * 8);
+                at[k] = (int)((16 + r) * g.sa + c * 8);
+            } else {
+                fdivmod((uint32_t)(i - g.c_w1), g.fd_kc2, r, c);
+                regs[k] = *reinterpret_cast<const bf16x8*>((const bf16*)p.W2 + (long)r * p.ldw2 + c * 8);
+                at[k] = (int)((16 + g.n1r) * g.sa + r * g.sw2 + c * 8);
+            }
+        }
+    }
+    // the epilogues' bias and mask values (first round of each product; later rounds read them where they are used)
+    const int nf1 = (p.N1 + 15) >> 4, nf2 = (p.N2 + 15) >> 4;
+    float b1v[4] = {0.f, 0.f, 0.f, 0.f}, b2v[3][4];
+    bool keep1[4] = {true, true, true, true};
+    {
+        const int nb = wave * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.bias1 && nb + r < p.N1) b1v[r] = p.bias1[nb + r];
+            if (p.relu_mask1 && row_ok && nb + r < p.N1) keep1[r] = (float)((const bf16*)p.relu_mask1)[m * p.ldmask1 + nb + r] > 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = (wave + 8 * q) * 16 + fq * 4 + r;
+                b2v[q][r] = (p.bias2 && n < p.N2) ? p.bias2[n] : 0.f;
+            }
+    }
+    // padding (k beyond K1 and N1, rows beyond M, N1 and N2) is zero: everything is cleared while the loads are on their way
+    {
+        const int words = ((16 + g.n1r) * g.sa + (g.n2r + 16) * g.sw2) / 8;
+        for (int i = tid; i < words; i += S2_THREADS) reinterpret_cast<bf16x8*>(s2_smem)[i] = zero8();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < S2_MAXC; ++k)
+        if (at[k] >= 0) *reinterpret_cast<bf16x8*>(As + at[k]) = regs[k];
+    __syncthreads();
+    // ---- product 1: a column fragment of H per wave
+    const int nk1 = (p.K1 + 31) >> 5;
+    for (int f = wave; f < nf1; f += 8) {
+        const bf16* arow = As + fr * g.sa + fq * 8;
+        const bf16* wrow = W1s + (f * 16 + fr) * g.sa + fq * 8;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        int ks = 0;
+        for (; ks + 1 < nk1; ks += 2) {
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(arow + ks * 32), fb0 = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(arow + ks * 32 + 32), fb1 = *reinterpret_cast<const bf16x8*>(wrow + ks * 32 + 32);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1, fa1, acc1, 0, 0, 0);
+        }
+        if (ks < nk1)
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + ks * 32), *reinterpret_cast<const bf16x8*>(arow + ks * 32), acc0, 0, 0, 0);
+        const int nb = f * 16 + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc0[r] + acc1[r];
+            if (f < 8) v += b1v[r];
+            else if (p.bias1 && nb + r < p.N1) v += p.bias1[nb + r];
+            v = small_act(v, p.act1);
+            if (f < 8) { if (!keep1[r]) v = 0.f; }
+            else if (p.relu_mask1 && row_ok && nb + r < p.N1 && !((float)((const bf16*)p.relu_mask1)[m * p.ldmask1 + nb + r] > 0.f)) v = 0.f;
+            o[r] = (bf16)((nb + r < p.N1) ? v : 0.f);
+        }
+        *reinterpret_cast<bf16x4*>(&Hs[fr * g.sw2 + nb]) = o;
+        if (row_ok && p.H) {
+            bf16* h = (bf16*)p.H + m * p.ldh + nb;
+            if (nb + 3 < p.N1 && (p.ldh & 3) == 0) *reinterpret_cast<bf16x4*>(h) = o;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < p.N1) h[r] = o[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- product 2
+    const int nk2 = ((p.N1 + 31) & ~31) >> 5;                          // at most 8 k-steps
+    bf16x8 ha[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ha[u] = u < nk2 ? *reinterpret_cast<const bf16x8*>(&Hs[fr * g.sw2 + u * 32 + fq * 8]) : zero8();
+    const float out_scale = p.out_scale != 0.f ? p.out_scale : 1.f;
+    int round = 0;
+    for (int f = wave; f < nf2; f += 8, ++round) {
+        const bf16* wrow = W2s + (f * 16 + fr) * g.sw2 + fq * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nk2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + u * 32), ha[u], acc, 0, 0, 0);
+        const int nb = f * 16 + fq * 4;
+        if (!row_ok || nb >= p.N2) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = acc[r];
+            if (round == 0) v[r] += b2v[0][r];
+            else if (round == 1) v[r] += b2v[1][r];
+            else if (round == 2) v[r] += b2v[2][r];
+            else if (p.bias2 && nb + r < p.N2) v[r] += p.bias2[nb + r];
+            v[r] = small_act(v[r], p.act2) * out_scale;
+        }
+        if (p.c_f32) {
+            float* c = (float*)p.C + m * p.ldc + nb;
+            if (nb + 3 < p.N2 && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < p.N2) c[r] = v[r];
+            }
+        } else {
+            bf16* c = (bf16*)p.C + m * p.ldc + nb;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+            if (nb + 3 < p.N2 && (p.ldc & 3) == 0) *reinterpret_cast<bf16x4*>(c) = o;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < p.N2) c[r] = o[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 __device__ __forceinline__ int rho(int m) {  // LDS row of tile row m: swap bits 2 and 3
     return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
@@ -1080,7 +1241,22 @@ extern "C" int stes_gemm_small2(const stes_gemm2_args* a, void* stream) {
     STES_CHECK(a->N1 <= 256 && a->K1 <= 1024 && a->N2 <= 1024, STES_ERR_UNSUPPORTED, "stes_gemm_small2: N1 <= 256, K1 <= 1024, N2 <= 1024");
     STES_CHECK(a->act1 >= 0 && a->act1 <= 2 && a->act2 >= 0 && a->act2 <= 2, STES_ERR_ARG, "stes_gemm_small2: act is 0, 1 or 2");
     STES_CHECK(a->M <= (1L << 31), STES_ERR_UNSUPPORTED, "stes_gemm_small2: too many rows");
-    hipLaunchKernelGGL(gemm_small2_kernel, dim3((unsigned)((a->M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *a);
+    // everything in LDS when it fits (the squeeze-excite pairs of stages 1 to 3 do, stage 4's 768-wide ones do not)
+    Small2Lds g;
+    const int k1p = (a->K1 + 31) & ~31, n1p = (a->N1 + 31) & ~31;
+    g.sa = k1p + 8; g.sw2 = n1p + 8;
+    g.n1r = (a->N1 + 15) & ~15; g.n2r = (a->N2 + 15) & ~15;
+    const int kc1 = a->K1 / 8, kc2 = a->N1 / 8;
+    g.c_a = 16 * kc1; g.c_w1 = g.c_a + a->N1 * kc1; g.c_all = g.c_w1 + a->N2 * kc2;
+    g.fd_kc1 = make_fastdiv(kc1); g.fd_kc2 = make_fastdiv(kc2);
+    const size_t lds = ((size_t)(16 + g.n1r) * g.sa + (size_t)(g.n2r + 16) * g.sw2) * 2;
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small2_lds_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static const bool lds_form = !(getenv("STES_SMALL2_LDS") && atoi(getenv("STES_SMALL2_LDS")) == 0);
+    if (lds_form && big_lds && lds <= 150 * 1024 && g.c_all <= S2_MAXC * S2_THREADS)
+        hipLaunchKernelGGL(gemm_small2_lds_kernel, dim3((unsigned)((a->M + 15) / 16)), dim3(S2_THREADS), lds, (hipStream_t)stream, *a, g);
+    else
+        hipLaunchKernelGGL(gemm_small2_kernel, dim3((unsigned)((a->M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *a);
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
