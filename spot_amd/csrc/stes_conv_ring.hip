@@ -665,11 +665,12 @@ bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
 
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
-    // (measured on 1,024 images against the window and column-strip kernels, forward / masked gradient: 7 x 7 x 768 48 vs 67 us and
-    // 51 vs 96; 28 x 28 x 128 107 vs 144 and 139 vs 175; 14 x 14 x 320 74 vs 73 and 93 vs 117 -- the 14-wide forward stays with the
-    // column-strip kernel.  With a request under a condition anywhere in the step all of these were slower than the kernels they
-    // replace: the waits then cover the rows asked for a moment ago.)
-    return on && stride == 1 && !pooled && (Wi == 7 || Wi == 28 || (Wi == 14 && mode == 1)) && (mode == 0 || mode == 1);
+    // (measured on 1,024 images against the window and column-strip kernels, forward / masked gradient, the kernel alone with its
+    // operands warm in the Infinity Cache: 7 x 7 x 768 48 vs 67 us and 51 vs 96; 28 x 28 x 128 107 vs 144 and 139 vs 175;
+    // 14 x 14 x 320 74 vs 73 and 93 vs 117 -- inside the training step, operands from memory, the 14-wide forward is 100 us with the
+    // column-strip kernel and the step 0.13 ms shorter with this one.  With a request under a condition anywhere in the step all
+    // of these were slower than the kernels they replace: the waits then cover the rows asked for a moment ago.)
+    return on && stride == 1 && !pooled && (Wi == 7 || Wi == 14 || Wi == 28) && (mode == 0 || mode == 1);
 }
 
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,

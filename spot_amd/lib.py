@@ -279,6 +279,7 @@ _KERNEL_OF = {
     # (stride-2 maps 112, 56, 28 or 14 wide of even height and stride-1 maps 7 wide go to the row-ring kernels: the rules of
     # stes_conv_ring_takes, stes_dgrad_ring_takes and stes_conv_ring1_takes)
     "stes_conv3x3g_fwd": (lambda a: "conv_ring1_kernel<7, 8, false>" if a[-2] == 1 and a[-5] == 7 else
+                          "conv_ring1_kernel<14, 4, false>" if a[-2] == 1 and a[-5] == 14 else
                           "conv_ring1_kernel<28, 2, false>" if a[-2] == 1 and a[-5] == 28 else
                           "conv3x3g_strip_kernel<true, 1>" if a[-2] == 1 and a[-5] <= 14 else
                           "conv_ring2_kernel<%d>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
