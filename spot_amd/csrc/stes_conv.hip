@@ -1107,12 +1107,13 @@ static int conv_launch(int mode, const uint16_t* src, const uint16_t* wp, uint16
     STES_CHECK(Ho == (Hi + 2 - 3) / stride + 1 && Wo == (Wi + 2 - 3) / stride + 1, STES_ERR_ARG, "stes_conv3x3g: output size does not match");
     STES_CHECK((scale == nullptr) == (shift == nullptr) && (col_sum == nullptr) == (col_sumsq == nullptr), STES_ERR_ARG, "stes_conv3x3g: paired pointers");
     if (stes_conv_ring1_takes(mode, stride, Wi, pool_out != nullptr))
-        return stes_conv_ring1_launch(mode, src, wp, dst, mask_raw, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
+        return stes_conv_ring1_launch(mode, src, wp, dst, mask_raw, scale, shift, col_sum, col_sumsq, pool_scale, pool_shift, pool_out, pool_norm, N,
+                                      Hi, Wi, C, stream);
     if (stes_conv_strip_takes(mode, stride, Wi))         // 14 x 14 and 7 x 7 maps, forward: operands straight from memory, no LDS window
         return stes_conv_strip_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream, pool_scale, pool_shift, pool_out,
                                       pool_norm);
     if (stes_conv_ring_takes(mode, stride, Hi, Wi, pool_out != nullptr))     // the strided forward of the large maps: read-each-pixel-2.25-times ring
-        return stes_conv_ring_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
+        return stes_conv_ring_launch(src, wp, dst, scale, shift, col_sum, col_sumsq, pool_scale, pool_shift, pool_out, pool_norm, N, Hi, Wi, C, stream);
     if (stes_dgrad_ring_takes(mode, stride, Hi, Wi))
         return stes_dgrad_ring_launch(src, wp, dst, mask_raw, scale, shift, col_sum, col_sumsq, N, Hi, Wi, C, stream);
     if (mode == 0 || stride == 1) {

@@ -5,8 +5,10 @@
 
 bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled);
 // Returns STES_OK or a negative error code.
+// With pool_out: the squeeze-excite squeeze of every image (mean of relu(pool_scale * out + pool_shift), bf16 [N][C]) instead of the sums.
 int stes_conv_ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
-                          float* col_sumsq, int N, int Hi, int Wi, int C, void* stream);
+                          float* col_sumsq, const float* pool_scale, const float* pool_shift, uint16_t* pool_out, float pool_norm, int N,
+                          int Hi, int Wi, int C, void* stream);
 
 // The input gradient of the same convolution (Hi x Wi = the gradient's map), with the ReLU mask and BatchNorm sums of
 // stes_conv3x3g_dgrad when mask_raw is given.
@@ -18,4 +20,5 @@ int stes_dgrad_ring_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx,
 // out = dX, with the mask and the BatchNorm backward sums when mask_raw is given), maps 28, 14 or 7 wide of any height.
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled);
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
-                           const float* shift, float* sum_a, float* sum_b, int N, int H, int W, int C, void* stream);
+                           const float* shift, float* sum_a, float* sum_b, const float* pool_scale, const float* pool_shift,
+                           uint16_t* pool_out, float pool_norm, int N, int H, int W, int C, void* stream);

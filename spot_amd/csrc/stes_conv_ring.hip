@@ -45,10 +45,14 @@ struct RingShape {
     static constexpr size_t LDS = (size_t)(4 * SLOT + WO * SPX) * 2;
 };
 
-template <int WI>
+// POOL (evaluation): the squeeze-excite squeeze of every image on the way out -- mean over its pixels of relu(pool_scale * out +
+// pool_shift), bf16 [N][C].  A wave owns its 16 channels for the whole image, so the sum needs no other wave.
+template <int WI, bool POOL>
 __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict__ in, const bf16* __restrict__ wp, bf16* __restrict__ out,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float* col_sum, float* col_sumsq, int N, int HI, int C, StesDet det) {
+                                                         float* col_sum, float* col_sumsq, const float* __restrict__ pool_scale,
+                                                         const float* __restrict__ pool_shift, bf16* __restrict__ pool_out, float pool_norm,
+                                                         int N, int HI, int C, StesDet det) {
     typedef RingShape<WI> S;
     extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
     bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [4][SLOT]
@@ -69,6 +73,9 @@ __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict_
     for (int e = 0; e < 8; ++e) { sc[e] = affine ? scale[cb + chunk * 8 + e] : 1.f; sh[e] = affine ? shift[cb + chunk * 8 + e] : 0.f; }
     const int ch0 = wave * 16 + 4 * fq;                                     // this lane's output channels within the slice
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    float ps[4], pb[4], psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ps[e] = POOL ? pool_scale[cb + ch0 + e] : 0.f; pb[e] = POOL ? pool_shift[cb + ch0 + e] : 0.f; }
     __syncthreads();
 
     // the workgroup's steps (image, output row) in one sequence, input rows requested two steps ahead -- across images too
@@ -148,7 +155,21 @@ __global__ __launch_bounds__(256) void conv_ring2_kernel(const bf16* __restrict_
                 *reinterpret_cast<bf16x4*>(stage + co * S::SPX + ch0) = ob;
                 if (live) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float fv = (float)ob[e]; ssum[e] += fv; ssq[e] += fv * fv; }
+                    for (int e = 0; e < 4; ++e) {
+                        const float fv = (float)ob[e];
+                        if constexpr (POOL) psum[e] += fmaxf(fv * ps[e] + pb[e], 0.f);
+                        else { ssum[e] += fv; ssq[e] += fv * fv; }
+                    }
+                }
+            }
+        }
+        if constexpr (POOL) {
+            if (live && ro == HO - 1) {                                    // the image's squeeze
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = cr_row16_sum(psum[e]) * pool_norm;
+                    if (fr == 0) pool_out[(long)n * C + cb + ch0 + e] = (bf16)t;
+                    psum[e] = 0.f;
                 }
             }
         }
@@ -412,11 +433,13 @@ struct Ring1Shape {
     static constexpr size_t LDS = (size_t)(NS * SLOT + R * W * PXS) * 2;
 };
 
-template <int W, int R, bool DGRAD>
+template <int W, int R, bool DGRAD, bool POOL>
 __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict__ in, const bf16* __restrict__ wp, bf16* __restrict__ out,
                                                          const bf16* __restrict__ mask_raw, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* sum_a, float* sum_b, int N, int H, int C,
-                                                         StesDet det) {
+                                                         const float* __restrict__ shift, float* sum_a, float* sum_b,
+                                                         const float* __restrict__ pool_scale, const float* __restrict__ pool_shift,
+                                                         bf16* __restrict__ pool_out, float pool_norm, int N, int H, int C, StesDet det) {
+    static_assert(!(DGRAD && POOL), "the squeeze belongs to the forward");
     typedef Ring1Shape<W, R> S;
     extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
     bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [NS][SLOT]
@@ -440,6 +463,9 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
         ssum[e] = 0.f; ssq[e] = 0.f;
     }
     const int ch0 = wave * 16 + 4 * fq;
+    float ps[4], pb[4], psum[4] = {0.f, 0.f, 0.f, 0.f};                     // POOL: see conv_ring2_kernel
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ps[e] = POOL ? pool_scale[cb + ch0 + e] : 0.f; pb[e] = POOL ? pool_shift[cb + ch0 + e] : 0.f; }
     __syncthreads();
 
     const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
@@ -513,6 +539,12 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[e];
                         *reinterpret_cast<bf16x4*>(stage + (rr * W + col) * S::PXS + ch0) = ob;
+                        if constexpr (POOL) {
+                            if (live && h0 + rr < H) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) psum[e] += fmaxf((float)ob[e] * ps[e] + pb[e], 0.f);
+                            }
+                        }
                     }
                 }
             }
@@ -542,8 +574,24 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
 #pragma unroll
                             for (int e = 0; e < 4; ++e) ob[e] = (bf16)acc[f][e];
                             *reinterpret_cast<bf16x4*>(stage + (rr * W + col) * S::PXS + ch0) = ob;
+                            if constexpr (POOL) {
+                                if (live) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) psum[e] += fmaxf((float)ob[e] * ps[e] + pb[e], 0.f);
+                                }
+                            }
                         }
                     }
+                }
+            }
+        }
+        if constexpr (POOL) {
+            if (live && t == HT - 1) {                                     // the image's squeeze
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = cr_row16_sum(psum[e]) * pool_norm;
+                    if (fr == 0) pool_out[(long)n * C + cb + ch0 + e] = (bf16)s;
+                    psum[e] = 0.f;
                 }
             }
         }
@@ -608,16 +656,17 @@ __global__ __launch_bounds__(256) void conv_ring1_kernel(const bf16* __restrict_
     }
 }
 
-template <int W, int R, bool DGRAD>
+template <int W, int R, bool DGRAD, bool POOL = false>
 int ring1_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale, const float* shift,
-                 float* sum_a, float* sum_b, int N, int H, int C, void* stream) {
+                 float* sum_a, float* sum_b, int N, int H, int C, void* stream, const float* pool_scale = nullptr,
+                 const float* pool_shift = nullptr, uint16_t* pool_out = nullptr, float pool_norm = 0.f) {
     typedef Ring1Shape<W, R> S;
     static_assert(S::NS * S::SLOT * 2 >= 4 * 128 * sizeof(float), "the statistics reduction reuses the ring");
     static_assert(S::LDS <= 64 * 1024, "within the default dynamic LDS limit");
     static int resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring1_kernel<W, R, DGRAD>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring1_kernel<W, R, DGRAD, POOL>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = per_cu * (cus < 1 ? 256 : cus);
     }
@@ -625,23 +674,24 @@ int ring1_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const ui
     int gx = resident / slices;
     if (gx < 1) gx = 1;
     if (gx > N) gx = N;
-    hipLaunchKernelGGL((conv_ring1_kernel<W, R, DGRAD>), dim3(gx, slices), dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp,
-                       (bf16*)out, (const bf16*)mask_raw, scale, shift, sum_a, sum_b, N, H, C, sum_a ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
+    hipLaunchKernelGGL((conv_ring1_kernel<W, R, DGRAD, POOL>), dim3(gx, slices), dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp,
+                       (bf16*)out, (const bf16*)mask_raw, scale, shift, sum_a, sum_b, pool_scale, pool_shift, (bf16*)pool_out, pool_norm, N, H, C, sum_a ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
 
-template <int WI>
+template <int WI, bool POOL>
 int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
-                float* col_sumsq, int N, int Hi, int C, void* stream) {
+                float* col_sumsq, const float* pool_scale, const float* pool_shift, uint16_t* pool_out, float pool_norm, int N, int Hi, int C,
+                void* stream) {
     typedef RingShape<WI> S;
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring2_kernel<WI>),
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring2_kernel<WI, POOL>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     STES_CHECK(big_lds, STES_ERR_UNSUPPORTED, "stes_conv3x3g: cannot raise the dynamic LDS limit");
     static int resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring2_kernel<WI>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_ring2_kernel<WI, POOL>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = per_cu * (cus < 1 ? 256 : cus);
     }
@@ -650,8 +700,8 @@ int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const flo
     if (gx < 1) gx = 1;
     if (gx > N) gx = N;
     const dim3 grid(gx, slices);
-    hipLaunchKernelGGL((conv_ring2_kernel<WI>), grid, dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp, (bf16*)out, scale,
-                       shift, col_sum, col_sumsq, N, Hi, C, col_sum ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
+    hipLaunchKernelGGL((conv_ring2_kernel<WI, POOL>), grid, dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)in, (const bf16*)wp, (bf16*)out, scale,
+                       shift, col_sum, col_sumsq, pool_scale, pool_shift, (bf16*)pool_out, pool_norm, N, Hi, C, col_sum ? stes_det_take(gx * slices) : StesDet{nullptr, 0u, 0u});
     STES_LAUNCH_CHECK();
     return STES_OK;
 }
@@ -660,7 +710,8 @@ int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const flo
 
 bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
-    return on && mode == 0 && stride == 2 && !pooled && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
+    (void)pooled;            // (with the squeeze-excite squeeze on the way out as well)
+    return on && mode == 0 && stride == 2 && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
 }
 
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {
@@ -670,12 +721,16 @@ bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {
     // 14 x 14 x 320 74 vs 73 and 93 vs 117 -- inside the training step, operands from memory, the 14-wide forward is 100 us with the
     // column-strip kernel and the step 0.13 ms shorter with this one.  With a request under a condition anywhere in the step all
     // of these were slower than the kernels they replace: the waits then cover the rows asked for a moment ago.)
-    return on && stride == 1 && !pooled && (Wi == 7 || Wi == 14 || Wi == 28) && (mode == 0 || mode == 1);
+    return on && stride == 1 && (!pooled || mode == 0) && (Wi == 7 || Wi == 14 || Wi == 28) && (mode == 0 || mode == 1);
 }
 
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
-                           const float* shift, float* sum_a, float* sum_b, int N, int H, int W, int C, void* stream) {
+                           const float* shift, float* sum_a, float* sum_b, const float* pool_scale, const float* pool_shift,
+                           uint16_t* pool_out, float pool_norm, int N, int H, int W, int C, void* stream) {
 #define RING1(WW, RR)                                                                                                                  \
+    if (W == WW && mode == 0 && pool_out)                                                                                              \
+        return ring1_launch<WW, RR, false, true>(in, wp, out, nullptr, scale, shift, nullptr, nullptr, N, H, C, stream, pool_scale, pool_shift, \
+                                                 pool_out, pool_norm);                                                                 \
     if (W == WW) return mode == 0 ? ring1_launch<WW, RR, false>(in, wp, out, nullptr, scale, shift, sum_a, sum_b, N, H, C, stream)     \
                                   : ring1_launch<WW, RR, true>(in, wp, out, mask_raw, scale, shift, sum_a, sum_b, N, H, C, stream)
     RING1(7, 8);
@@ -700,10 +755,16 @@ int stes_dgrad_ring_launch(const uint16_t* dy, const uint16_t* wp, uint16_t* dx,
 }
 
 int stes_conv_ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
-                          float* col_sumsq, int N, int Hi, int Wi, int C, void* stream) {
-    if (Wi == 112) return ring_launch<112>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
-    if (Wi == 56) return ring_launch<56>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
-    if (Wi == 28) return ring_launch<28>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
-    if (Wi == 14) return ring_launch<14>(in, wp, out, scale, shift, col_sum, col_sumsq, N, Hi, C, stream);
+                          float* col_sumsq, const float* pool_scale, const float* pool_shift, uint16_t* pool_out, float pool_norm, int N,
+                          int Hi, int Wi, int C, void* stream) {
+#define RING2(WW)                                                                                                                           \
+    if (Wi == WW)                                                                                                                           \
+        return pool_out ? ring_launch<WW, true>(in, wp, out, scale, shift, nullptr, nullptr, pool_scale, pool_shift, pool_out, pool_norm, N, Hi, C, stream) \
+                        : ring_launch<WW, false>(in, wp, out, scale, shift, col_sum, col_sumsq, nullptr, nullptr, nullptr, 0.f, N, Hi, C, stream)
+    RING2(112);
+    RING2(56);
+    RING2(28);
+    RING2(14);
+#undef RING2
     return stes_set_error(STES_ERR_UNSUPPORTED, "stes_conv_ring: map width");
 }

@@ -239,6 +239,9 @@ def _conv_bytes(a):
     return 2 * c * n * (hi * wi + ho * wo)
 
 
+_RING1_ROWS = {7: 8, 14: 4, 28: 2}         # stride-1 row-ring kernel: map width -> rows per step (stes_conv_ring1_launch)
+
+
 def _ring2(a):
     n, hi, wi, ho, wo, stride, c = a[-7:]
     return stride == 2 and hi % 2 == 0 and wi in (112, 56, 28, 14)
@@ -278,16 +281,13 @@ _KERNEL_OF = {
     # (stride-1 maps of at most 14 columns go to the column-strip kernel: the rule of stes_conv_strip_takes)
     # (stride-2 maps 112, 56, 28 or 14 wide of even height and stride-1 maps 7 wide go to the row-ring kernels: the rules of
     # stes_conv_ring_takes, stes_dgrad_ring_takes and stes_conv_ring1_takes)
-    "stes_conv3x3g_fwd": (lambda a: "conv_ring1_kernel<7, 8, false>" if a[-2] == 1 and a[-5] == 7 else
-                          "conv_ring1_kernel<14, 4, false>" if a[-2] == 1 and a[-5] == 14 else
-                          "conv_ring1_kernel<28, 2, false>" if a[-2] == 1 and a[-5] == 28 else
+    "stes_conv3x3g_fwd": (lambda a: "conv_ring1_kernel<%d, %d, false, false>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
                           "conv3x3g_strip_kernel<true, 1>" if a[-2] == 1 and a[-5] <= 14 else
-                          "conv_ring2_kernel<%d>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
-    "stes_conv3x3g_fwd_pool": (lambda a: "conv3x3g_strip_kernel<true, 3>" if a[-2] == 1 and a[-5] <= 14 else
-                               "conv3x3g_rows_kernel<%d, false, true>" % a[-2], _conv_bytes),
-    "stes_conv3x3g_dgrad": (lambda a: "conv_ring1_kernel<7, 8, true>" if a[-2] == 1 and a[-5] == 7 else
-                            "conv_ring1_kernel<14, 4, true>" if a[-2] == 1 and a[-5] == 14 else
-                            "conv_ring1_kernel<28, 2, true>" if a[-2] == 1 and a[-5] == 28 else
+                          "conv_ring2_kernel<%d, false>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
+    "stes_conv3x3g_fwd_pool": (lambda a: "conv_ring1_kernel<%d, %d, false, true>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
+                               "conv3x3g_strip_kernel<true, 3>" if a[-2] == 1 and a[-5] <= 14 else
+                               "conv_ring2_kernel<%d, true>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false, true>" % a[-2], _conv_bytes),
+    "stes_conv3x3g_dgrad": (lambda a: "conv_ring1_kernel<%d, %d, true, false>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
                             "conv3x3g_rows_kernel<1, true>" if a[-2] == 1 else
                             "dgrad_ring2_kernel<%d>" % a[-5] if _ring2(a) else
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
