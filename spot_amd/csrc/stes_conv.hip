@@ -1275,6 +1275,7 @@ extern "C" int stes_conv3x3g_wgrad(const uint16_t* dout, const uint16_t* in, con
     STES_CHECK(dout && in && dw, STES_ERR_ARG, "stes_conv3x3g_wgrad: null pointer");
     STES_CHECK(C % 64 == 0 && (stride == 1 || stride == 2), STES_ERR_ARG, "stes_conv3x3g_wgrad: C % 64, stride 1|2");
     STES_CHECK(Ho == (Hi + 2 - 3) / stride + 1 && Wo == (Wi + 2 - 3) / stride + 1, STES_ERR_ARG, "stes_conv3x3g_wgrad: output size does not match");
+    if (stes_wgrad_ring_takes(stride, Wi)) return stes_wgrad_ring_launch(dout, in, in_scale, in_shift, dw, N, Hi, Wi, C, stream);
     const int th = stes_div_up(Ho, TH), tw = stes_div_up(Wo, TW);
     const int n_items = N * th * tw;
     const int gy = C / 64;

@@ -22,3 +22,8 @@ bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled);
 int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uint16_t* out, const uint16_t* mask_raw, const float* scale,
                            const float* shift, float* sum_a, float* sum_b, const float* pool_scale, const float* pool_shift,
                            uint16_t* pool_out, float pool_norm, int N, int H, int W, int C, void* stream);
+
+// The weight gradient at stride 1 on maps 28, 14 or 7 wide (dw [C][16][3][3] fp32, added to): each input pixel fetched once.
+bool stes_wgrad_ring_takes(int stride, int Wi);
+int stes_wgrad_ring_launch(const uint16_t* dout, const uint16_t* in, const float* scale, const float* shift, float* dw, int N, int H, int W,
+                           int C, void* stream);

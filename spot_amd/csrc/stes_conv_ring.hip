@@ -680,6 +680,200 @@ int ring1_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const ui
     return STES_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient, stride 1
+// dW[co][ci][a][b] += sum over pixels of dY[h][w][co] * x[h + a - 1][w + b - 1][ci] with x = ReLU(BatchNorm(raw input)): per
+// group a 16 x 16 product per tap whose reduction runs over pixels, so both MFMA operands are wanted pixel-major while memory
+// is channel-major -- the transposing LDS read (ds_read_tr16_b64: 16 lanes read 4 pixels x 16 channels, each lane leaves with
+// 4 pixels of one channel) does that turn.  The tile kernel of stes_conv.hip stages a 4 x 8 pixel tile and its 6 x 10 halo per
+// reduction step, so at stride 1 an input pixel is fetched 1.9 times (532 MB counted against 257 MB on the 14 x 14 maps).  Here
+// the workgroup walks the image rows as the forward kernel does: input rows in the ring (each fetched once), the step's dY
+// rows beside them, and a reduction block of 32 pixel slots (one row of a 28-wide map, two rows of 14, four rows of 7; unused
+// slots point the dY operand at a zero pixel) takes 2 + 18 transposing reads and 9 MFMAs.  The 9 accumulators stay in registers
+// over all the workgroup's images and leave through the atomics of the tile kernel.
+template <int W, int R>
+struct WgradRingShape {
+    typedef Ring1Shape<W, R> In;                            // the input ring is the forward kernel's
+    static constexpr int RPB = W > 16 ? 1 : W > 8 ? 2 : 4;  // rows per reduction block of 32 slots
+    static constexpr int SPR = 32 / RPB;                    // slots per row
+    static constexpr int NB = R / RPB;                      // reduction blocks per step
+    static constexpr int YCH = R * W * 8, YPT = (YCH + 255) / 256;
+    static constexpr int RING = In::NS * In::SLOT, STG = R * W * In::PXS;     // elements
+    static constexpr size_t USED = (size_t)(RING + STG + In::PXS) * 2;       // + the zero pixel
+    static constexpr size_t LDS = USED > 4608 * sizeof(float) ? USED : 4608 * sizeof(float);      // the result layout reuses it all
+    static_assert(R % RPB == 0 && W <= SPR, "whole reduction blocks per step");
+};
+
+template <int W, int R>
+__global__ __launch_bounds__(256) void wgrad_ring1_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ dw, int N, int H, int C, StesDet det) {
+    typedef WgradRingShape<W, R> S;
+    typedef Ring1Shape<W, R> I;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
+    bf16* ring = reinterpret_cast<bf16*>(cr_smem);                          // [NS][SLOT]
+    bf16* stage = ring + S::RING;                                           // dY rows of the step: [R][W][PXS]
+    bf16* zpix = stage + S::STG;                                            // a pixel of zeros
+    float* red = reinterpret_cast<float*>(cr_smem);                         // [2 groups][16 co][16 ci][9] at the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int slice = blockIdx.y, cb = slice * 64, HT = (H + R - 1) / R;
+    for (int i = tid; i < (S::RING + S::STG + I::PXS) / 2; i += 256) reinterpret_cast<unsigned*>(ring)[i] = 0u;
+    const int chunk = tid & 7;
+    const bool affine = scale != nullptr;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = affine ? scale[cb + chunk * 8 + e] : 1.f; sh[e] = affine ? shift[cb + chunk * 8 + e] : 0.f; }
+    // this lane's two pixel slots of a reduction block (a transposing read takes slots 8 fq + fr / 4 and that + 4) and its four channels
+    const int cc = wave * 16 + 4 * (fr & 3);
+    int s_row[2], s_px[2];
+    bool s_ok[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int slot = 8 * fq + (fr >> 2) + 4 * hh;
+        s_row[hh] = slot / S::SPR;
+        const int px = slot - s_row[hh] * S::SPR;
+        s_ok[hh] = px < W;
+        s_px[hh] = min(px, W - 1);
+    }
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int nimg = blockIdx.x < N ? (N - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int total = nimg * HT;
+    // (every request is made by every thread on every step and unwanted results are dropped, so that the waits are counted
+    // in instructions: see the stride-2 forward kernel)
+    int in_n = blockIdx.x, in_t = 0;
+    auto fetch_in = [&](bf16x8 (&dst)[I::IPT]) {
+        const bf16* src = in + ((long)min(in_n, N - 1) * H + R * in_t) * W * C + cb + chunk * 8;
+        const int last = (H - R * in_t) * W - 1;
+#pragma unroll
+        for (int k = 0; k < I::IPT; ++k) {
+            const int i = k < I::ICH / 256 ? tid + 256 * k : min(tid + 256 * k, I::ICH - 1);
+            const int p = i >> 3, c = p / W;                                // chunk row c: input row R t + c
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)min(p, last) * C);
+            dst[k] = (c == 0 ? in_t == 0 : R * in_t + c < H) ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (++in_t == HT) { in_t = 0; in_n += gridDim.x; }
+    };
+    int y_n = blockIdx.x, y_t = 0;
+    auto fetch_y = [&](bf16x8 (&dst)[S::YPT]) {
+        const bf16* src = dout + ((long)min(y_n, N - 1) * H + R * y_t) * W * C + cb + chunk * 8;
+        const int pix = min(R, H - R * y_t) * W;
+#pragma unroll
+        for (int k = 0; k < S::YPT; ++k) {
+            const int i = k < S::YCH / 256 ? tid + 256 * k : min(tid + 256 * k, S::YCH - 1);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)min(i >> 3, pix - 1) * C);
+            dst[k] = (i >> 3) < pix ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (++y_t == HT) { y_t = 0; y_n += gridDim.x; }
+    };
+    int t = 0;
+    auto step = [&](bf16x8 (&raw)[I::IPT], bf16x8 (&gy)[S::YPT], bool live) {
+        const int h0 = R * t;
+        if (t == 0) {                                                       // row -1 of an image: zeros
+            for (int i = tid; i < W * 32; i += 256) reinterpret_cast<unsigned*>(ring + ((i >> 5) + 1) * I::PXS)[i & 31] = 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < I::IPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < I::ICH) {
+                const int p = i >> 3, c = p / W, px = p - c * W;
+                if (c > 0 || t == 0) {
+                    bf16x8 v = raw[k];
+                    if (affine && h0 + c < H) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f);
+                    }
+                    *reinterpret_cast<bf16x8*>(ring + ((h0 + c + 1) & (I::NS - 1)) * I::SLOT + (px + 1) * I::PXS + chunk * 8) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S::YPT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S::YCH) *reinterpret_cast<bf16x8*>(stage + (i >> 3) * I::PXS + chunk * 8) = live ? gy[k] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        fetch_in(raw);
+        fetch_y(gy);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < S::NB; ++u) {
+            if (h0 + u * S::RPB < H) {                                      // (rows below the image hold zeros in both operands anyway)
+                const int r0 = u * S::RPB + s_row[0], r1 = u * S::RPB + s_row[1];
+                const bf16* ya = s_ok[0] ? stage + (r0 * W + s_px[0]) * I::PXS + cc : zpix + (cc & 15);
+                const bf16* yb = s_ok[1] ? stage + (r1 * W + s_px[1]) * I::PXS + cc : zpix + (cc & 15);
+                const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)ya);
+                const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)yb);
+                const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const bf16* xa = ring + ((h0 + r0 + a) & (I::NS - 1)) * I::SLOT + s_px[0] * I::PXS + cc;
+                    const bf16* xb = ring + ((h0 + r1 + a) & (I::NS - 1)) * I::SLOT + s_px[1] * I::PXS + cc;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xa + b * I::PXS));
+                        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + b * I::PXS));
+                        const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[a * 3 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[a * 3 + b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (++t == HT) t = 0;
+    };
+    bf16x8 rawA[I::IPT], rawB[I::IPT], gyA[S::YPT], gyB[S::YPT];
+    fetch_in(rawA);
+    fetch_y(gyA);
+    fetch_in(rawB);
+    fetch_y(gyB);
+#pragma unroll 1
+    for (int s = 0; s < total; s += 2) {                                    // (an odd count ends with a step on zero dY rows)
+        step(rawA, gyA, true);
+        step(rawB, gyB, s + 1 < total);
+    }
+    // result -> LDS in the checkpoint layout [co][ci][tap] of this workgroup's 64 channels, two groups at a time, then
+    // contiguous atomics (the tile kernel's way out)
+    float* dst = dw + (long)slice * 9216;
+    det_enter(det);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((wave >> 1) == h) {
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave & 1) * 16 + fq * 4 + r) * 16 + fr) * 9 + tt] = acc[tt][r];
+        }
+        __syncthreads();
+        for (int i = tid; i < 4608; i += 256) atomicAdd(dst + h * 4608 + i, red[i]);
+        __syncthreads();
+    }
+    det_leave(det);
+}
+
+template <int W, int R>
+int wgrad_ring1_launch(const uint16_t* dout, const uint16_t* in, const float* scale, const float* shift, float* dw, int N, int H, int C,
+                       void* stream) {
+    typedef WgradRingShape<W, R> S;
+    static_assert(S::LDS <= 64 * 1024, "within the default dynamic LDS limit");
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_ring1_kernel<W, R>, 256, S::LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = per_cu * (cus < 1 ? 256 : cus);
+    }
+    const int slices = C / 64;
+    int gx = resident / slices;
+    if (gx < 1) gx = 1;
+    if (gx > N) gx = N;
+    hipLaunchKernelGGL((wgrad_ring1_kernel<W, R>), dim3(gx, slices), dim3(256), S::LDS, (hipStream_t)stream, (const bf16*)dout, (const bf16*)in, scale,
+                       shift, dw, N, H, C, stes_det_take(gx * slices));
+    STES_LAUNCH_CHECK();
+    return STES_OK;
+}
+
 template <int WI, bool POOL>
 int ring_launch(const uint16_t* in, const uint16_t* wp, uint16_t* out, const float* scale, const float* shift, float* col_sum,
                 float* col_sumsq, const float* pool_scale, const float* pool_shift, uint16_t* pool_out, float pool_norm, int N, int Hi, int C,
@@ -712,6 +906,21 @@ bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
     (void)pooled;            // (with the squeeze-excite squeeze on the way out as well)
     return on && mode == 0 && stride == 2 && Hi % 2 == 0 && (Wi == 112 || Wi == 56 || Wi == 28 || Wi == 14);
+}
+
+bool stes_wgrad_ring_takes(int stride, int Wi) {
+    // (alone on 1,024 images: 28 x 28 x 128 101 vs 126 us, 14 x 14 x 320 69 vs 85, 7 x 7 x 768 52 vs 61; the step with the weight
+    // gradients in program order 35.05 vs 35.19 ms, with them on the side stream unchanged -- what it saves there is traffic)
+    static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
+    return on && stride == 1 && (Wi == 14 || Wi == 28 || Wi == 7);
+}
+
+int stes_wgrad_ring_launch(const uint16_t* dout, const uint16_t* in, const float* scale, const float* shift, float* dw, int N, int H, int W,
+                           int C, void* stream) {
+    if (W == 28) return wgrad_ring1_launch<28, 2>(dout, in, scale, shift, dw, N, H, C, stream);
+    if (W == 14) return wgrad_ring1_launch<14, 4>(dout, in, scale, shift, dw, N, H, C, stream);
+    if (W == 7) return wgrad_ring1_launch<7, 8>(dout, in, scale, shift, dw, N, H, C, stream);
+    return stes_set_error(STES_ERR_UNSUPPORTED, "stes_wgrad_ring: map width");
 }
 
 bool stes_conv_ring1_takes(int mode, int stride, int Wi, bool pooled) {

@@ -292,7 +292,8 @@ _KERNEL_OF = {
                             "dgrad_ring2_kernel<%d>" % a[-5] if _ring2(a) else
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
-    "stes_conv3x3g_wgrad": ("conv3x3g_wgrad_kernel", _conv_bytes),
+    "stes_conv3x3g_wgrad": (lambda a: "wgrad_ring1_kernel<%d, %d>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
+                            "conv3x3g_wgrad_kernel", _conv_bytes),
     # (x, x_is_u8, mean, std, w, patches, out, sums..., e_scale, e_shift, e_slice, e_slice_n, B, T, Tv, Cin, H, W)
     "stes_stem_conv": (lambda a: "stem_conv_kernel<%s, %s>" % ("true" if a[1] else "false", "true" if a[9] is not None else "false"),
                        _stem_bytes),

@@ -60,6 +60,8 @@ def close(a, b, rtol=1e-2, atol=1e-2):
                                                # the stride-1 row-ring kernel (7 wide, eight rows a step): fewer rows than a step, two
                                                # steps, a last step of one row
                                                (1, 5, 7, 64, 40), (1, 16, 7, 128, 300), (1, 9, 7, 64, 3),
+                                               # the row-ring weight gradient (stride 1; 28, 14, 7 wide): heights that end inside a step
+                                               # and inside a reduction block of two or four rows
                                                (1, 9, 14, 64, 5), (1, 3, 28, 64, 4), (1, 14, 14, 320, 700)])
 def test_conv3x3g(stride, H, W, C, N):
     from spot_amd import lib
