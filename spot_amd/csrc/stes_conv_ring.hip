@@ -909,7 +909,7 @@ bool stes_conv_ring_takes(int mode, int stride, int Hi, int Wi, bool pooled) {
 }
 
 bool stes_wgrad_ring_takes(int stride, int Wi) {
-    // (alone on 1,024 images: 28 x 28 x 128 101 vs 126 us, 14 x 14 x 320 69 vs 85, 7 x 7 x 768 52 vs 61; the step with the weight
+    // (alone on 1,024 images: 28 x 28 x 128 101 vs 126 us, 14 x 14 x 320 64 vs 85, 7 x 7 x 768 52 vs 61; the step with the weight
     // gradients in program order 35.05 vs 35.19 ms, with them on the side stream unchanged -- what it saves there is traffic)
     static const int on = getenv("STES_CONV_RING") ? atoi(getenv("STES_CONV_RING")) : 1;
     return on && stride == 1 && (Wi == 14 || Wi == 28 || Wi == 7);
@@ -918,7 +918,7 @@ bool stes_wgrad_ring_takes(int stride, int Wi) {
 int stes_wgrad_ring_launch(const uint16_t* dout, const uint16_t* in, const float* scale, const float* shift, float* dw, int N, int H, int W,
                            int C, void* stream) {
     if (W == 28) return wgrad_ring1_launch<28, 2>(dout, in, scale, shift, dw, N, H, C, stream);
-    if (W == 14) return wgrad_ring1_launch<14, 4>(dout, in, scale, shift, dw, N, H, C, stream);
+    if (W == 14) return wgrad_ring1_launch<14, 8>(dout, in, scale, shift, dw, N, H, C, stream);       // (64 us; 70 at four rows a step, 74 at two)
     if (W == 7) return wgrad_ring1_launch<7, 8>(dout, in, scale, shift, dw, N, H, C, stream);
     return stes_set_error(STES_ERR_UNSUPPORTED, "stes_wgrad_ring: map width");
 }
@@ -942,7 +942,9 @@ int stes_conv_ring1_launch(int mode, const uint16_t* in, const uint16_t* wp, uin
                                                  pool_out, pool_norm);                                                                 \
     if (W == WW) return mode == 0 ? ring1_launch<WW, RR, false>(in, wp, out, nullptr, scale, shift, sum_a, sum_b, N, H, C, stream)     \
                                   : ring1_launch<WW, RR, true>(in, wp, out, mask_raw, scale, shift, sum_a, sum_b, N, H, C, stream)
+    // (14 wide, rows per step: forward 68 us at eight, 72 at four, 85 at two; masked gradient 100 / 93 / 110)
     RING1(7, 8);
+    if (mode == 0) { RING1(14, 8); }
     RING1(14, 4);
     RING1(28, 2);
 #undef RING1

@@ -239,7 +239,8 @@ def _conv_bytes(a):
     return 2 * c * n * (hi * wi + ho * wo)
 
 
-_RING1_ROWS = {7: 8, 14: 4, 28: 2}         # stride-1 row-ring kernel: map width -> rows per step (stes_conv_ring1_launch)
+_RING1_ROWS = {7: 8, 14: 4, 28: 2}         # stride-1 row-ring kernel: map width -> rows per step (stes_conv_ring1_launch),
+_RING1_ROWS_FWD = {7: 8, 14: 8, 28: 2}     # ... of the forward and of the weight gradient
 
 
 def _ring2(a):
@@ -281,10 +282,10 @@ _KERNEL_OF = {
     # (stride-1 maps of at most 14 columns go to the column-strip kernel: the rule of stes_conv_strip_takes)
     # (stride-2 maps 112, 56, 28 or 14 wide of even height and stride-1 maps 7 wide go to the row-ring kernels: the rules of
     # stes_conv_ring_takes, stes_dgrad_ring_takes and stes_conv_ring1_takes)
-    "stes_conv3x3g_fwd": (lambda a: "conv_ring1_kernel<%d, %d, false, false>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
+    "stes_conv3x3g_fwd": (lambda a: "conv_ring1_kernel<%d, %d, false, false>" % (a[-5], _RING1_ROWS_FWD[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
                           "conv3x3g_strip_kernel<true, 1>" if a[-2] == 1 and a[-5] <= 14 else
                           "conv_ring2_kernel<%d, false>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false>" % a[-2], _conv_bytes),
-    "stes_conv3x3g_fwd_pool": (lambda a: "conv_ring1_kernel<%d, %d, false, true>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
+    "stes_conv3x3g_fwd_pool": (lambda a: "conv_ring1_kernel<%d, %d, false, true>" % (a[-5], _RING1_ROWS_FWD[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
                                "conv3x3g_strip_kernel<true, 3>" if a[-2] == 1 and a[-5] <= 14 else
                                "conv_ring2_kernel<%d, true>" % a[-5] if _ring2(a) else "conv3x3g_rows_kernel<%d, false, true>" % a[-2], _conv_bytes),
     "stes_conv3x3g_dgrad": (lambda a: "conv_ring1_kernel<%d, %d, true, false>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
@@ -292,7 +293,7 @@ _KERNEL_OF = {
                             "dgrad_ring2_kernel<%d>" % a[-5] if _ring2(a) else
                             "conv3x3g_dgrad2_kernel<%s>" % ("true" if a[3] is not None else "false"),
                             lambda a: _conv_bytes(a) + 2 * a[-1] * a[-7] * a[-6] * a[-5] * (a[3] is not None)),
-    "stes_conv3x3g_wgrad": (lambda a: "wgrad_ring1_kernel<%d, %d>" % (a[-5], _RING1_ROWS[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
+    "stes_conv3x3g_wgrad": (lambda a: "wgrad_ring1_kernel<%d, %d>" % (a[-5], _RING1_ROWS_FWD[a[-5]]) if a[-2] == 1 and a[-5] in _RING1_ROWS else
                             "conv3x3g_wgrad_kernel", _conv_bytes),
     # (x, x_is_u8, mean, std, w, patches, out, sums..., e_scale, e_shift, e_slice, e_slice_n, B, T, Tv, Cin, H, W)
     "stes_stem_conv": (lambda a: "stem_conv_kernel<%s, %s>" % ("true" if a[1] else "false", "true" if a[9] is not None else "false"),
@@ -393,7 +394,7 @@ def _gemm_kernel(a):
                  and (not a.a_scale or 8 * a.K <= 16 * (nb * 2 + 16)) and (not a.a_gate or (a.a_scale and a.gate_group >= 32)))
     if stream_ok:
         return ("gemm_stream_wg_kernel" if a.wg_dw else "gemm_stream_tail_kernel" if a.e_scale else "gemm_stream_kernel") + "<%d, %d, %d, %d, %d, %d>" % (
-            (nb // 16, 8 if nb >= 128 else 4, pro) + _RING[a.K])
+            (nb // 16, 8 if nb >= 128 else 4, pro) + ((10, 2, 1) if a.K == 320 and pro == 0 else _RING[a.K]))    # (no prologue: two K = 320 tiles fit the ring)
     if (not a.a_scale and not a.a_gate and a.k0 == 0 and a.map_stride <= 1 and not a.col_sum and a.n_split == 0
             and a.M * a.N * a.K <= (1 << 28) and a.M <= 16 * 65535):
         return "gemm_small_kernel"
