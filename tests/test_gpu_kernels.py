@@ -139,6 +139,37 @@ def test_conv3x3g(stride, H, W, C, N):
     close(dw, wref.grad, 1e-2, 2e-2 * math.sqrt(N * Ho * Wo))
 
 
+@pytest.mark.parametrize("stride,H,W,C,N", [(2, 28, 28, 64, 5), (2, 14, 14, 128, 7), (1, 14, 14, 64, 9), (1, 7, 7, 128, 11), (1, 28, 28, 64, 3)])
+def test_conv3x3g_row_ring_without_input_transform_and_without_sums(stride, H, W, C, N):
+    """The row-ring kernels with their optional parts off: no BatchNorm + ReLU on the way in, no sums on the way out (forward
+    and weight gradient on the raw input), and the same launch twice gives the same bits (a workgroup's images follow one
+    another through one ring: nothing of an earlier image may be left in it)."""
+    from spot_amd import lib
+    g = torch.Generator().manual_seed(11)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = bfr(N, C, H, W, g=g)
+    w = torch.randn(C, 16, 3, 3, generator=g) * 0.1
+    xin = x.float().requires_grad_(True)
+    wref = w.to(BF).float().requires_grad_(True)
+    ref = F.conv2d(xin, wref, stride=stride, padding=1, groups=C // 16)
+    gy = bfr(*ref.shape, g=g)
+    ref.backward(gy.float())
+    wp_f = torch.empty(C // 16 * 5 * 512, dtype=BF, device="cuda"); wp_d = torch.empty_like(wp_f)
+    lib.call("stes_pack_conv3x3g", lib.ptr(dev(w)), lib.ptr(wp_f), lib.ptr(wp_d), C // 16, stride)
+    xd, gyd = dev(nhwc(x)), dev(nhwc(gy))
+    outs = []
+    for _ in range(2):
+        out = torch.full((N * Ho * Wo, C), 3.0, dtype=BF, device="cuda")
+        lib.call("stes_conv3x3g_fwd", lib.ptr(xd), lib.ptr(wp_f), lib.ptr(out), None, None, None, None, N, H, W, Ho, Wo, stride, C)
+        outs.append(out)
+    dw = torch.zeros(C, 16, 3, 3, device="cuda")
+    lib.call("stes_conv3x3g_wgrad", lib.ptr(gyd), lib.ptr(xd), None, None, lib.ptr(dw), N, H, W, Ho, Wo, stride, C)
+    torch.cuda.synchronize()
+    close(nchw(outs[0].cpu(), N, Ho, Wo), ref.detach(), 1e-2, 2e-2)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    close(dw, wref.grad, 1e-2, 2e-2 * math.sqrt(N * Ho * Wo))
+
+
 def test_gru_one_launch_timeout_is_loud():
     """A wait of the one-launch GRU recurrence that runs out must not pass unnoticed: with the spin bound at zero (every wait
     runs out) the outputs carry NaN and the next stes_gru_* call reports the failure; with
